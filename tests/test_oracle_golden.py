@@ -1,0 +1,136 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the REFERENCE's own modules
+(tools/make_golden.py, run in the build container). CPU-only: runs under -m "not gpu"."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import config as ocfg, sam, support, retrieval, model as omodel
+from tests.golden_util import load, make_inputs, moments
+
+torch.set_grad_enabled(False)
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def close(a, b, **kw):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, **(kw or TOL))
+
+
+@pytest.mark.parametrize("tag", ["win14", "glob16"])
+def test_sam_attention(tag):
+    g = load(f"sam_attention_{tag}")
+    S, dim, heads = int(g["S"]), int(g["dim"]), int(g["heads"])
+    cfg = dict(dim=dim, heads=heads, depth=1, global_idx=(0,), window=14, img=S * 16, patch=16, out=16)
+    spec = {k: v for k, v in ocfg.sam_encoder_spec(cfg, "e.").items() if k.startswith("e.blocks.0.attn.")}
+    sd = ocfg.random_state(spec, int(g["seed_params"]))
+    x = make_inputs(int(g["seed_inputs"]), x=(3, S, S, dim))["x"]
+    close(sam.vit_attention(sd, "e.blocks.0.attn.", x, heads), g["y"])
+
+
+@pytest.mark.parametrize("tag", ["window", "global"])
+def test_sam_block(tag):
+    g = load(f"sam_block_{tag}")
+    dim, heads, grid, win = int(g["dim"]), int(g["heads"]), int(g["g"]), int(g["window"])
+    cfg = dict(dim=dim, heads=heads, depth=1, global_idx=(0,) if win == 0 else (), window=14, img=grid * 16, patch=16, out=16)
+    spec = {k: v for k, v in ocfg.sam_encoder_spec(cfg, "e.").items() if k.startswith("e.blocks.0.")}
+    sd = ocfg.random_state(spec, int(g["seed_params"]))
+    x = make_inputs(int(g["seed_inputs"]), x=(2, grid, grid, dim))["x"]
+    close(sam.vit_block(sd, "e.blocks.0.", x, heads, win), g["y"])
+
+
+@pytest.mark.parametrize("tag", ["img256", "img1024"])
+def test_sam_encoder(tag):
+    g = load(f"sam_encoder_{tag}")
+    cfg = dict(dim=int(g["dim"]), heads=int(g["heads"]), depth=int(g["depth"]), global_idx=tuple(int(i) for i in g["global_idx"]),
+               window=14, img=int(g["img"]), patch=16, out=int(g["out"]))
+    sd = ocfg.random_state(ocfg.sam_encoder_spec(cfg), int(g["seed_params"]))
+    x = make_inputs(int(g["seed_inputs"]), x=(int(g["B"]), 3, cfg["img"], cfg["img"]))["x"]
+    y = sam.image_encoder(sd, x, cfg)
+    close(y, g["y"], rtol=5e-4, atol=5e-5)
+    close(moments(y), g["y_moments"], rtol=1e-5, atol=1e-7)
+
+
+def test_mask_decoder_and_prompt_encoder():
+    g = load("mask_decoder")
+    sd = ocfg.random_state(dict(ocfg.mask_decoder_spec(), **ocfg.prompt_encoder_spec()), int(g["seed_params"]))
+    inp = make_inputs(int(g["seed_inputs"]), emb=(2, 256, 64, 64), sparse=(2, 1, 256))
+    pe = sam.dense_pe(sd)
+    close(pe[..., ::4, ::4], g["dense_pe"], rtol=1e-4, atol=2e-5)
+    close(moments(pe), g["dense_pe_moments"], rtol=1e-5, atol=1e-7)
+    dense = sam.dense_no_mask(sd, 2)
+    close(dense[:, :, 0, 0], g["no_mask"])
+    for mm in (0, 1):
+        masks, iou, keys = sam.mask_decoder(sd, inp["emb"], pe, inp["sparse"], dense, bool(mm))
+        close(masks[..., ::4, ::4], g[f"masks_{mm}"], rtol=1e-3, atol=1e-3)
+        close(moments(masks), g[f"masks_moments_{mm}"], rtol=1e-4, atol=1e-6)
+        close(iou, g[f"iou_{mm}"], rtol=1e-3, atol=1e-4)
+    src = keys.transpose(1, 2).reshape(2, 256, 64, 64)   # mask_decoder.py:132 view
+    close(src[..., ::4, ::4], g["src"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("D,grid", [(768, 24), (1024, 24), (1152, 27)])
+def test_mask_adapter_pooling(D, grid):
+    g = load(f"mask_adapter_D{D}")
+    sd = ocfg.random_state(ocfg.mask_adapter_spec(D, "mp."), int(g["seed_params"]))
+    inp = make_inputs(int(g["seed_inputs"]), feat=(2, D, grid, grid), mask=("mask", 2, 384))
+    close(support.bilinear_resize(inp["mask"], grid, grid), g["mask_small"], rtol=1e-5, atol=1e-6)
+    y, maps = support.mask_adapter_pooling(sd, inp["feat"], inp["mask"], "mp.", return_maps=True)
+    close(maps, g["maps"], rtol=1e-3, atol=1e-4)
+    close(y, g["y"], rtol=1e-3, atol=1e-5)
+
+
+def test_masked_pooling():
+    g = load("masked_pooling")
+    inp = make_inputs(int(g["seed_inputs"]), feat=(2, 768, 24, 24), mask=("mask", 2, 384))
+    close(support.masked_pooling(inp["feat"], inp["mask"]), g["y"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("D", [768, 1024])
+def test_cir_fuse(D):
+    g = load(f"cir_fuse_D{D}")
+    sd = ocfg.random_state(ocfg.fuse_spec(D, "f."), int(g["seed_params"]))
+    inp = make_inputs(int(g["seed_inputs"]), img=(4, D), txt=(4, D))
+    close(support.cir_fuse(sd, inp["img"], inp["txt"], "f."), g["y"], rtol=1e-4, atol=1e-6)
+
+
+def test_region_embedding_and_cosine():
+    g = load("region_embedding")
+    inp = make_inputs(int(g["seed_inputs"]), emb=(3, 256, 64, 64), mask=("mask", 3, 256), feat=(3, 1, 256))
+    r = retrieval.region_embedding(inp["emb"], inp["mask"])
+    close(r, g["y"], rtol=1e-4, atol=1e-6)
+    close(retrieval.cosine(r, torch.nn.functional.normalize(inp["feat"], dim=-1)), g["cos"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("pooling", ["MaskAdapterPooling", "MaskedPooling"])
+def test_toplevel_forward(pooling):
+    """The reference's own glue (build_model.py / sam_with_sup_branch.py / support_branch.py), run in the build
+    container through an in-memory open_clip stand-in with a 2-block SigLIP (tools/make_golden.py gen_toplevel)."""
+    g = load(f"toplevel_{pooling}")
+    spec = ocfg.model_spec("sam_base", "ViT-B-16-SigLIP-384", pooling)
+    spec = {k: v for k, v in spec.items() if "attn_pool" not in k and not (".siglip." in k and any(
+        f".blocks.{i}." in k or f".resblocks.{i}." in k for i in range(2, 12)))}
+    spec["support_branch.siglip.model.text.token_embedding.weight"] = (512, 768)
+    assert sorted(spec) == [str(k) for k in g["keys"]]          # reference state_dict keys == oracle inventory
+    sd = ocfg.random_state(spec, int(g["seed_params"]))
+    inp = make_inputs(int(g["seed_inputs"]), q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 512),
+                      mask=("mask", 1, 384))
+    import oracle.config as c
+    name = "ViT-B-16-SigLIP-384"
+    saved = dict(c.SIGLIP[name])
+    c.SIGLIP[name] = dict(saved, depth=2, t_depth=2, vocab=512)
+    try:
+        for mm in (1, 0):
+            masks, emb, feat = omodel.forward(sd, "sam_base", name, pooling, inp["q"], inp["s"], inp["text"], inp["mask"], bool(mm))
+            close(masks[..., ::4, ::4], g[f"masks_{mm}"], rtol=2e-3, atol=2e-3)
+            close(moments(masks), g[f"masks_moments_{mm}"], rtol=1e-3, atol=1e-4)
+        close(emb[..., ::4, ::4], g["emb"], rtol=2e-3, atol=2e-4)
+        close(feat, g["feat"], rtol=1e-3, atol=1e-5)
+    finally:
+        c.SIGLIP[name] = saved
+
+
+def test_state_dict_inventory_matches_reference():
+    keys = [str(k) for k in load("state_dict_keys_sam_base")["keys"]]
+    spec = ocfg.model_spec("sam_base", "ViT-B-16-SigLIP-384", "MaskedPooling")
+    mine = sorted(k for k in spec if ".siglip." not in k)
+    assert mine == keys
