@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py — CORE retrieval-time forward on MI355X: query triplets/sec (forward + gallery similarity + top-k).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): SAM-ViT-B + SigLIP-B/16-384 + MaskAdapterPooling, batch 32 triplets per GPU,
+bf16 fast mode, synthetic inputs / random-init weights, 10k-row bf16 gallery (N=1). For N>1 (configs[2]) a 100k-row
+gallery is row-sharded over the ranks, queries are all-gathered over RCCL, each rank scores all queries against its
+shard, per-shard top-k lists are merged on the host. A "step" = one such pass; inputs are resident in HBM.
+One JSON line on rank 0. `roofline` is for the dominant kernel (the bf16 MFMA GEMM); `cpu_baseline` is the CPU oracle
+timed on the host cores on a bounded sample (1 triplet) at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
+    ap.add_argument("--gallery", type=int, default=0, help="total gallery rows (default 10k at N=1, 100k at N>1)")
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--sam", default="sam_base")
+    ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (fp32 PyTorch-CPU restatement of the reference, pinned by tests/golden) on ONE triplet of the
+    same workload + similarity vs the same gallery size. kind = "port"."""
+    from oracle import config as ocfg, model as omodel, retrieval as oret
+    from tests.golden_util import make_inputs
+    torch.set_num_threads(os.cpu_count() or 1)
+    spec = ocfg.model_spec(args.sam, args.siglip, "MaskAdapterPooling")
+    sd = ocfg.random_state(spec, seed=0)
+    inp = make_inputs(1, q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 32000), mask=("mask", 1, 384))
+    G = torch.nn.functional.normalize(torch.randn(args.gallery or 10000, 256), dim=-1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        masks, emb, feat = omodel.forward(sd, args.sam, args.siglip, "MaskAdapterPooling", inp["q"], inp["s"], inp["text"], inp["mask"], True)
+        oret.similarity_topk(feat[:, 0], G, args.topk)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 triplet (SAM-B+SigLIP-B/16 fp32 forward + {G.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+
+    from cor_amd import ops, retrieval, utils
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+
+    T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = build_model_with_query_support_feat(args.sam, args.siglip, None, None, "MaskAdapterPooling")
+    utils.randomize_parameters(model, seed=0)
+    model = model.to(dev).eval()
+    model.compute_dtype = T
+    B = args.batch
+    batch = utils.synthetic_batch(B, dev, seed=rank)
+    Gtot = args.gallery or (10000 if world == 1 else 100000)
+    lo, hi = retrieval.shard_bounds(Gtot, world, rank)
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    rows = torch.nn.functional.normalize(torch.randn((Gtot, 256), generator=gen), dim=-1)[lo:hi]
+    shard = retrieval.GalleryShard(rows.to(dev), offset=lo, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+
+    def step():
+        masks, emb, feat = model(**batch, multimask_output=True)
+        return retrieval.distributed_search(feat[:, 0], shard, args.topk)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.GEMM_PROFILE = prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # dominant kernel: the MFMA GEMM. HIP events were recorded around every launch on the launch stream.
+    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, dt_ in prof if dt_ == T)
+    gemm_flops = sum(f for _, _, f, dt_ in prof if dt_ == T)
+    n_launch = sum(1 for p in prof if p[3] == T)
+    peak = 2500.0 if T == torch.bfloat16 else 157.3
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+
+    if rank == 0:
+        res = {
+            "metric": "query triplets/sec (forward + similarity + top-k)", "value": world * B * args.steps / dt, "unit": "triplets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.sam}+{args.siglip}+MaskAdapterPooling, {B} triplets/GPU, {Gtot}-row {args.dtype} gallery"
+                                   + (f" sharded {world} ways (RCCL all-gather of queries, host top-k merge)" if world > 1 else ""),
+                       "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_mfma<{args.dtype}>", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "launches_per_step": n_launch // max(args.steps, 1),
+                         "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

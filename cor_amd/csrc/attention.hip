@@ -1,0 +1,243 @@
+// cor_amd — attention kernels for gfx950.
+//
+// attn_rowlane: exact-fp32 flash-style attention, ONE QUERY PER LANE. q and the output accumulator live in
+// registers (2*HD VGPRs); keys/values are wave-uniform addresses, so they arrive through the scalar cache
+// (s_load) or as broadcast vector loads and cost no LDS and no barrier; online softmax over chunks of 8 keys.
+// It serves (a) the fp32 parity mode of every attention on the path, (b) the decoder's tiny attentions
+// (6 tokens <-> 4096 tokens, hd 16/32) in both modes, (c) head sizes the MFMA kernel does not take (hd 72).
+// SAM's decomposed relative position bias is folded in: per key ROW kh the lane computes q.Rh[qh-kh+S-1] once,
+// and q.Rw[qw-kw+S-1] for all kw is precomputed per lane into LDS ([S][128] floats, lane-strided: conflict-free).
+// Window partition / zero padding / unpartition are pure addressing (padded tokens read the qkv bias row).
+//
+// The bf16 MFMA flash kernels (hd = 64) live in flash_attn.hip.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const void* q; const void* k; const void* v; void* o;
+  long q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;   // element strides: batch, token
+  int H, Tq, Tk;
+  float scale;
+  // SAM
+  const void* pad_row;                 // [3*H*HD] (q|k|v) in T
+  const float* rel_h; const float* rel_w;
+  int S;                               // rel-pos grid (window size, or grid for global)
+  int grid, nW;                        // window mode: image grid and windows per side
+};
+
+constexpr int NT = 128;                // threads (= queries) per block
+
+template <typename T, int HD>
+__device__ __forceinline__ float dot_q(const float (&q)[HD], const T* __restrict__ p) {
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < HD / 4; ++i) {
+    const f32x4 kv = ld4<T>(p + 4 * i);
+    a0 = fmaf(q[4 * i + 0], kv[0], a0); a1 = fmaf(q[4 * i + 1], kv[1], a1);
+    a0 = fmaf(q[4 * i + 2], kv[2], a0); a1 = fmaf(q[4 * i + 3], kv[3], a1);
+  }
+  return a0 + a1;
+}
+
+// MODE 0: plain strided MHA. MODE 1: SAM global (rel-pos, S = grid). MODE 2: SAM windowed (rel-pos, S = window).
+template <typename T, typename TO, int HD, int MODE>
+__global__ void __launch_bounds__(NT) attn_rowlane(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rw_lds[];   // [S][NT], MODE != 0
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y;
+  const int bz = blockIdx.z;
+  const int S = a.S;
+  int t = blockIdx.x * NT + tid;
+  bool valid = t < a.Tq;
+  if (!valid) t = a.Tq - 1;
+
+  const T* qbase = (const T*)a.q; const T* kbase = (const T*)a.k; const T* vbase = (const T*)a.v;
+  const T* pad = (const T*)a.pad_row;
+  const int d3 = 3 * a.H * HD;         // SAM qkv row length
+  int qh = 0, qw = 0;
+  long orow = 0;                       // output row (tokens) for SAM modes
+  const T* qp;
+  int b = bz, wy = 0, wx = 0;
+  if (MODE == 0) {
+    qp = qbase + bz * a.q_sb + (long)t * a.q_st + h * HD;
+  } else if (MODE == 1) {
+    qh = t / S; qw = t - qh * S;
+    orow = (long)bz * a.Tq + t;
+    qp = qbase + orow * d3 + h * HD;
+  } else {
+    const int nw2 = a.nW * a.nW;
+    b = bz / nw2; const int wi = bz - b * nw2; wy = wi / a.nW; wx = wi - wy * a.nW;
+    qh = t / S; qw = t - qh * S;
+    const int y = wy * S + qh, x = wx * S + qw;
+    if (y >= a.grid || x >= a.grid) valid = false;
+    orow = ((long)b * a.grid + min(y, a.grid - 1)) * a.grid + min(x, a.grid - 1);
+    qp = valid ? qbase + orow * d3 + h * HD : pad + h * HD;
+  }
+
+  float q[HD], o[HD];
+#pragma unroll
+  for (int i = 0; i < HD / 4; ++i) {
+    const f32x4 v4 = ld4<T>(qp + 4 * i);
+    q[4 * i] = v4[0]; q[4 * i + 1] = v4[1]; q[4 * i + 2] = v4[2]; q[4 * i + 3] = v4[3];
+  }
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+
+  if (MODE != 0) {
+    for (int kw = 0; kw < S; ++kw) rw_lds[kw * NT + tid] = dot_q<float, HD>(q, a.rel_w + (long)(qw - kw + S - 1) * HD);
+    // each lane reads back only its own column: no barrier needed
+  }
+
+  float m = -INFINITY, l = 0.f;
+  const int rows = MODE == 0 ? 1 : S;
+  const int cols = MODE == 0 ? a.Tk : S;
+  for (int kh = 0; kh < rows; ++kh) {
+    float rh = 0.f;
+    if (MODE != 0) rh = dot_q<float, HD>(q, a.rel_h + (long)(qh - kh + S - 1) * HD);
+    for (int c0 = 0; c0 < cols; c0 += 8) {
+      const int n = min(8, cols - c0);
+      float s[8];
+      const T* vps[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        s[jj] = -INFINITY; vps[jj] = vbase;
+        if (jj < n) {                  // wave-uniform
+          const int kw = c0 + jj;
+          const T* kp;
+          if (MODE == 0) {
+            kp = kbase + bz * a.k_sb + (long)kw * a.k_st + h * HD;
+            vps[jj] = vbase + bz * a.v_sb + (long)kw * a.v_st + h * HD;
+          } else if (MODE == 1) {
+            const long krow = (long)bz * a.Tk + kh * S + kw;
+            kp = kbase + krow * d3 + h * HD; vps[jj] = vbase + krow * d3 + h * HD;
+          } else {
+            const int y = wy * S + kh, x = wx * S + kw;
+            if (y < a.grid && x < a.grid) {
+              const long krow = ((long)b * a.grid + y) * a.grid + x;
+              kp = kbase + krow * d3 + h * HD; vps[jj] = vbase + krow * d3 + h * HD;
+            } else {
+              kp = pad + a.H * HD + h * HD; vps[jj] = pad + 2 * a.H * HD + h * HD;
+            }
+          }
+          float sc = dot_q<T, HD>(q, kp) * a.scale;
+          if (MODE != 0) sc += rh + rw_lds[kw * NT + tid];
+          s[jj] = sc;
+        }
+      }
+      float mx = m;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) mx = fmaxf(mx, s[jj]);
+      const float alpha = __expf(m - mx);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] *= alpha;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        if (jj < n) {
+          const float p = __expf(s[jj] - mx);
+          l += p;
+          const T* vp = vps[jj];
+#pragma unroll
+          for (int i = 0; i < HD / 4; ++i) {
+            const f32x4 vv = ld4<T>(vp + 4 * i);
+            o[4 * i] = fmaf(p, vv[0], o[4 * i]); o[4 * i + 1] = fmaf(p, vv[1], o[4 * i + 1]);
+            o[4 * i + 2] = fmaf(p, vv[2], o[4 * i + 2]); o[4 * i + 3] = fmaf(p, vv[3], o[4 * i + 3]);
+          }
+        }
+      }
+      m = mx;
+    }
+  }
+  if (!valid) return;
+  const float inv = 1.0f / l;
+  TO* op = MODE == 0 ? (TO*)a.o + bz * a.o_sb + (long)t * a.o_st + h * HD : (TO*)a.o + orow * (long)(a.H * HD) + h * HD;
+#pragma unroll
+  for (int i = 0; i < HD / 4; ++i) {
+    f32x4 r = {o[4 * i] * inv, o[4 * i + 1] * inv, o[4 * i + 2] * inv, o[4 * i + 3] * inv};
+    st4<TO>(op + 4 * i, r);
+  }
+}
+
+template <typename T, typename TO, int HD, int MODE>
+int launch_rowlane(const AttnArgs& a, int nb, hipStream_t s) {
+  const size_t lds = MODE == 0 ? 0 : (size_t)a.S * NT * sizeof(float);
+  if (lds > 64 * 1024) return COR_ENOSUPPORT;
+  hipLaunchKernelGGL((attn_rowlane<T, TO, HD, MODE>), dim3(cdiv(a.Tq, NT), a.H, nb), dim3(NT), lds, s, a);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int HD, int MODE>
+int dispatch_types(const AttnArgs& a, int nb, int dtype, int out_dtype, hipStream_t s) {
+  if (dtype == COR_F32 && out_dtype == COR_F32) return launch_rowlane<float, float, HD, MODE>(a, nb, s);
+  if (dtype == COR_BF16 && out_dtype == COR_BF16) return launch_rowlane<bf16_t, bf16_t, HD, MODE>(a, nb, s);
+  if (dtype == COR_BF16 && out_dtype == COR_F32) return launch_rowlane<bf16_t, float, HD, MODE>(a, nb, s);
+  if (dtype == COR_F32 && out_dtype == COR_BF16) return launch_rowlane<float, bf16_t, HD, MODE>(a, nb, s);
+  return COR_ENOSUPPORT;
+}
+
+}  // namespace
+
+// bf16 MFMA kernels (flash_attn.hip); return COR_ENOSUPPORT when the shape is not theirs.
+int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb,
+                         long v_st, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale,
+                         hipStream_t s);
+int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w,
+                       int B, int H, int grid, int window, hipStream_t s);
+
+extern "C" int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb,
+                             long v_st, int dtype, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk,
+                             int hd, float scale, void* stream) {
+  if (!q || !k || !v || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return COR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == COR_BF16 && hd == 64 && Tq >= 64 && Tk >= 64) {
+    const int rc = cor_flash_plain_bf16(q, q_sb, q_st, k, k_sb, k_st, v, v_sb, v_st, out, o_sb, o_st, out_dtype, B, H, Tq, Tk, scale, s);
+    if (rc != COR_ENOSUPPORT) return rc;
+  }
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = out;
+  a.q_sb = q_sb; a.q_st = q_st; a.k_sb = k_sb; a.k_st = k_st; a.v_sb = v_sb; a.v_st = v_st; a.o_sb = o_sb; a.o_st = o_st;
+  a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.S = 0;
+  switch (hd) {
+    case 16: return dispatch_types<16, 0>(a, B, dtype, out_dtype, s);
+    case 32: return dispatch_types<32, 0>(a, B, dtype, out_dtype, s);
+    case 64: return dispatch_types<64, 0>(a, B, dtype, out_dtype, s);
+    case 72: return dispatch_types<72, 0>(a, B, dtype, out_dtype, s);
+    default: return COR_ENOSUPPORT;
+  }
+}
+
+template <int HD>
+static int sam_rowlane(AttnArgs a, int B, int grid, int window, int dtype, int out_dtype, hipStream_t s) {
+  a.scale = 1.0f / sqrtf((float)HD);
+  if (window == 0) {
+    a.S = grid; a.Tq = a.Tk = grid * grid; a.nW = 1;
+    return dispatch_types<HD, 1>(a, B, dtype, out_dtype, s);
+  }
+  a.S = window; a.Tq = a.Tk = window * window; a.nW = (grid + window - 1) / window;
+  return dispatch_types<HD, 2>(a, B * a.nW * a.nW, dtype, out_dtype, s);
+}
+
+extern "C" int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, const void* pad_row, const float* rel_h,
+                                 const float* rel_w, int B, int H, int hd, int grid, int window, void* stream) {
+  if (!qkv || !out || !rel_h || !rel_w || B <= 0 || H <= 0 || grid <= 0 || window < 0) return COR_EINVAL;
+  if (window > 0 && !pad_row) return COR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == COR_BF16 && hd == 64) {
+    const int rc = cor_flash_sam_bf16(qkv, out, out_dtype, pad_row, rel_h, rel_w, B, H, grid, window, s);
+    if (rc != COR_ENOSUPPORT) return rc;
+  }
+  const int HD = hd;
+  const long d = (long)H * HD;
+  const size_t esz = dtype == COR_F32 ? 4 : 2;
+  AttnArgs a{};
+  a.q = qkv; a.k = (const char*)qkv + d * esz; a.v = (const char*)qkv + 2 * d * esz; a.o = out;
+  a.H = H; a.pad_row = pad_row; a.rel_h = rel_h; a.rel_w = rel_w; a.grid = grid;
+  switch (hd) {
+    case 16: return sam_rowlane<16>(a, B, grid, window, dtype, out_dtype, s);
+    case 32: return sam_rowlane<32>(a, B, grid, window, dtype, out_dtype, s);
+    case 64: return sam_rowlane<64>(a, B, grid, window, dtype, out_dtype, s);
+    default: return COR_ENOSUPPORT;
+  }
+}

@@ -1,0 +1,85 @@
+"""Retrieval end of the path: region embeddings, gallery similarity + top-k, gallery sharding across ranks.
+
+The reference has no gallery / top-k code; the definitions come from its only region-vs-query
+similarity, the training loss: region embedding = utils/loss_func.py:35-56 (mask_pooling), query = comb_support_feat
+(lib/support_branch.py:85), score = F.cosine_similarity (utils/loss_func.py:84) = dot product of unit vectors.
+Order: score descending, then global gallery index ascending.
+
+Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU tests):
+the gallery is row-sharded, rank r owning rows [r*ceil(G/R), ...). One exchange step on the data path: an
+all-gather of the [B_local, 256] query embeddings (<= 64 KB per rank: latency-bound). Each rank then scores
+ALL queries against its shard with the HIP kernel (cor_similarity_topk), and the per-shard (score, global index)
+lists ([B_total, k] each) are gathered and merged on the host by (score desc, index asc).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def region_embedding(embeddings: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """ref: utils/loss_func.py:35-56. embeddings f32[B,C,H,W] (query_image_embeddings), mask f32[B,1,h,w] in [0,1]
+    -> f32[B,1,C] unit-norm. HIP: cor_bilinear (clamped) + cor_masked_pool (NCHW, L2-normalised)."""
+    B, C, H, W = embeddings.shape
+    emb = embeddings.to(torch.float32).contiguous()
+    m = mask.to(torch.float32).contiguous()
+    if tuple(m.shape[-2:]) != (H, W):
+        m = ops.bilinear(m, H, W)
+    return ops.masked_pool(emb, m, B, H * W, C, feat_nchw=True, clamp01=True, l2norm=True).view(B, 1, C)
+
+
+def merge_topk_host(scores_parts, idx_parts, k: int):
+    """Host merge of per-shard lists by (score desc, index asc). parts: lists of CPU tensors [Bq, k_i]."""
+    s = torch.cat(scores_parts, dim=1)
+    i = torch.cat(idx_parts, dim=1)
+    i_key = torch.where(i < 0, torch.full_like(i, torch.iinfo(torch.int64).max), i)   # missing entries last
+    o1 = torch.sort(i_key, dim=1, stable=True).indices
+    s, i = torch.gather(s, 1, o1), torch.gather(i, 1, o1)
+    o2 = torch.sort(s, dim=1, descending=True, stable=True).indices[:, :k]
+    return torch.gather(s, 1, o2), torch.gather(i, 1, o2)
+
+
+class GalleryShard:
+    """Rows [offset, offset + n) of a unit-norm gallery, resident in HBM as fp32 / bf16 / fp16."""
+
+    def __init__(self, rows: torch.Tensor, offset: int = 0, dtype: torch.dtype | None = None):
+        if not rows.is_cuda:
+            raise RuntimeError("GalleryShard lives in GPU memory (no CPU path)")
+        self.rows = rows.to(dtype or rows.dtype).contiguous()
+        self.offset = int(offset)
+
+    def __len__(self):
+        return self.rows.shape[0]
+
+    def search(self, queries: torch.Tensor, k: int):
+        """queries f32[Bq,C] (unit-norm) -> (scores f32[Bq,k], global idx i64[Bq,k]) on the GPU."""
+        q = queries.reshape(-1, queries.shape[-1]).to(torch.float32).contiguous()
+        return ops.similarity_topk(q, self.rows, k, g_offset=self.offset)
+
+
+def shard_bounds(n_rows: int, world: int, rank: int):
+    per = -(-n_rows // world)
+    lo = min(rank * per, n_rows)
+    return lo, min(lo + per, n_rows)
+
+
+def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int, group=None):
+    """All ranks call this with their own queries [B_local, C] and their gallery shard.
+    Returns on EVERY rank (scores f32[B_total,k], idx i64[B_total,k]) as CPU tensors, queries ordered by rank.
+    Collectives: all_gather(queries) on the device, all_gather_object-free gather of the small result lists."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        s, i = shard.search(local_queries, k)
+        return s.cpu(), i.cpu()
+    world = dist.get_world_size(group)
+    q = local_queries.reshape(-1, local_queries.shape[-1]).to(torch.float32).contiguous()
+    gathered = [torch.empty_like(q) for _ in range(world)]
+    dist.all_gather(gathered, q, group=group)                    # the one data-path collective (RCCL over xGMI)
+    allq = torch.cat(gathered, dim=0)
+    s, i = shard.search(allq, k)                                 # local shard vs ALL queries
+    s_parts = [torch.empty_like(s) for _ in range(world)]
+    i_parts = [torch.empty_like(i) for _ in range(world)]
+    dist.all_gather(s_parts, s, group=group)                     # 12 B * B_total * k per rank
+    dist.all_gather(i_parts, i, group=group)
+    return merge_topk_host([t.cpu() for t in s_parts], [t.cpu() for t in i_parts], k)

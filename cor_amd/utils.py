@@ -1,0 +1,53 @@
+"""Small host-side helpers (synthetic parameters / inputs for benchmarks; no arithmetic on the forward path)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+@torch.no_grad()
+def randomize_parameters(model: torch.nn.Module, seed: int = 0) -> None:
+    """Seeded NON-degenerate parameters for benchmarking with synthetic weights (the reference's defaults are
+    degenerate: zero pos_embed / rel_pos, gamma 1e-6 — SURVEY.md section 7). Matrices ~ N(0, 1/fan_in) so
+    activations stay O(1) through depth; LayerNorm scales / gamma ~ U(0.5, 1.5); biases and embeddings small."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+        if not p.dtype.is_floating_point or name in ("pixel_mean", "pixel_std"):
+            continue
+        leaf = name.rsplit(".", 1)[-1]
+        shp = tuple(p.shape)
+        if leaf == "gamma" or (leaf == "weight" and p.dim() == 1):
+            v = torch.rand(shp, generator=gen) + 0.5
+        elif leaf == "bias":
+            v = torch.randn(shp, generator=gen) * 0.1
+        elif leaf in ("pos_embed", "positional_embedding", "rel_pos_h", "rel_pos_w", "latent"):
+            v = torch.randn(shp, generator=gen) * 0.5
+        elif p.dim() <= 1 or "embedding" in name or "token" in name or "gaussian" in name or "no_mask" in name:
+            v = torch.randn(shp, generator=gen)
+        else:
+            fan_in = math.prod(shp[1:])
+            if "output_upscaling" in name and p.dim() == 4:
+                fan_in = shp[0]
+            v = torch.randn(shp, generator=gen) / math.sqrt(max(fan_in, 1))
+        p.copy_(v.to(p.device, p.dtype))
+    if hasattr(model, "invalidate_packed"):
+        model.invalidate_packed()
+
+
+def synthetic_batch(B: int, device, seed: int = 0, vocab: int = 32000):
+    """SURVEY 8d inputs: N(0,1) images at model size, 4-20 random token ids then pad id 1, one rectangle mask."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    q = torch.randn((B, 3, 1024, 1024), generator=gen)
+    s = torch.randn((B, 3, 384, 384), generator=gen)
+    text = torch.ones((B, 64), dtype=torch.int64)
+    mask = torch.zeros((B, 1, 384, 384))
+    for b in range(B):
+        n = int(torch.randint(4, 21, (1,), generator=gen))
+        text[b, :n] = torch.randint(2, vocab, (n,), generator=gen)
+        h, w = (int(v) for v in torch.randint(96, 272, (2,), generator=gen))
+        y0 = int(torch.randint(0, 384 - h + 1, (1,), generator=gen))
+        x0 = int(torch.randint(0, 384 - w + 1, (1,), generator=gen))
+        mask[b, 0, y0:y0 + h, x0:x0 + w] = 1.0
+    return dict(query_image_inputs=q.to(device), support_image_inputs=s.to(device), change_text_inputs=text.to(device),
+                support_mask_inputs=mask.to(device))

@@ -1,0 +1,95 @@
+"""CPU-side checks (run under -m "not gpu"): the C-ABI library loads and exports every symbol include/cor_amd.h
+declares, the product's parameter tree equals the reference's state_dict key inventory, the factory's error
+behaviour, and the host-side top-k merge. No compute call is made (no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _built():
+    return os.path.exists(os.path.join(ROOT, "cor_amd", "csrc", "libcor_amd.so"))
+
+
+def test_library_exports_every_declared_symbol():
+    if not _built():
+        import __graft_entry__ as g
+        g.build()
+    from cor_amd import _native
+    lib = _native.load()
+    hdr = open(os.path.join(ROOT, "include", "cor_amd.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|long)\s+(cor_\w+)\s*\(", hdr, flags=re.M)))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libcor_amd.so does not export {name}"
+    assert sorted(_native.SIGNATURES) == declared, "ctypes table and header disagree"
+    assert lib.cor_version() >= 1
+
+
+def test_product_fails_loudly_without_gpu():
+    from cor_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 16), torch.zeros(4, 16))
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    m = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskedPooling").eval()
+    with pytest.raises(RuntimeError):
+        m(query_image_inputs=torch.zeros(1, 3, 1024, 1024), support_image_inputs=torch.zeros(1, 3, 384, 384),
+          change_text_inputs=torch.ones(1, 64, dtype=torch.long), support_mask_inputs=torch.zeros(1, 1, 384, 384))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cor_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_state_dict_keys_match_reference():
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    ref = [str(k) for k in load("state_dict_keys_sam_base")["keys"]]
+    m = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskedPooling")
+    mine = sorted(k for k in m.state_dict() if ".siglip." not in k)
+    assert mine == ref
+    g = load("toplevel_MaskAdapterPooling")
+    m = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskAdapterPooling")
+    mine = set(m.state_dict())
+    refk = set(str(k) for k in g["keys"])
+    assert {k for k in refk if ".siglip." not in k} == {k for k in mine if ".siglip." not in k}
+    assert {k for k in refk if ".siglip." in k} <= mine      # stand-in SigLIP (2 blocks, no MAP head) is a subset
+
+
+@pytest.mark.parametrize("kw,msg", [(dict(sam_model="sam_tiny"), "Invalid SAM model"),
+                                    (dict(siglip_model="ViT-L-14"), "Invalid SigLIP model"),
+                                    (dict(mask_pooling="AvgPool"), "Invalid mask pooling method")])
+def test_factory_error_behaviour(kw, msg):
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    args = dict(sam_model="sam_base", siglip_model="ViT-B-16-SigLIP-384", mask_pooling="MaskedPooling")
+    args.update(kw)
+    with pytest.raises(ValueError, match=msg):
+        build_model_with_query_support_feat(**args)
+
+
+def test_host_topk_merge_matches_oracle():
+    from cor_amd import retrieval
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(0)
+    Q = torch.from_numpy(rng.standard_normal((5, 256), dtype=np.float32))
+    G = torch.from_numpy(rng.standard_normal((300, 256), dtype=np.float32))
+    G[17] = G[250]                       # a tie across shards
+    full_s, full_i = oret.similarity_topk(Q, G, 8)
+    parts_s, parts_i = [], []
+    for r in range(4):
+        lo, hi = retrieval.shard_bounds(300, 4, r)
+        s, i = oret.similarity_topk(Q, G[lo:hi], 8)
+        parts_s.append(s); parts_i.append(i + lo)
+    s, i = retrieval.merge_topk_host(parts_s, parts_i, 8)
+    assert torch.equal(i, full_i) and torch.allclose(s, full_s)
+    s2, i2 = oret.merge_topk(list(zip(parts_s, parts_i)), 8)
+    assert torch.equal(i2, full_i)

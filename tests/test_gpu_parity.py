@@ -1,0 +1,465 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel / stage / the whole forward, called through the
+C ABI (cor_amd.ops -> libcor_amd.so), against (a) golden vectors produced by the REFERENCE's own modules and
+(b) the CPU oracle on seeded inputs. Tolerances are stated per test: fp32 (exact-MFMA) mode is held to the
+north-star 1e-3; bf16 mode has its own, looser, documented budget.
+
+Every comparison also lands in gpurun_out/parity_report.jsonl (max abs / rel error) for DESIGN.md."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import config as ocfg, sam as osam, siglip as osig, support as osup, retrieval as oret, model as omodel
+from tests.golden_util import load, make_inputs
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+DEV = "cuda:0"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def _ops():
+    from cor_amd import ops, engine
+    return ops, engine
+
+
+def report(name, got, ref, rtol, atol):
+    got = got.detach().float().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(np.asarray(got)).float()
+    ref = ref.detach().float().cpu() if isinstance(ref, torch.Tensor) else torch.as_tensor(np.asarray(ref)).float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs()
+    rec = dict(name=name, max_abs=float(err.max()), max_ref=float(ref.abs().max()), mean_abs=float(err.mean()),
+               rel_l2=float((got - ref).norm() / (ref.norm() + 1e-30)), finite=bool(torch.isfinite(got).all()), rtol=rtol, atol=atol)
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    bad = err > (atol + rtol * ref.abs())
+    assert rec["finite"], f"{name}: non-finite output"
+    assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.numel()} out of tolerance; {rec}"
+    return rec
+
+
+def dev(sd):
+    return {k: v.to(DEV) for k, v in sd.items()}
+
+
+def packer(sd, T):
+    _, engine = _ops()
+    return engine._Packer(dev(sd), T)
+
+
+# ======================================================================================================
+# library / ABI
+# ======================================================================================================
+def test_native_library_is_the_one_in_tree():
+    from cor_amd import _native
+    lib = _native.load()
+    assert lib.cor_version() >= 1
+    assert os.path.samefile(_native.LIB_PATH, os.path.join(ROOT, "cor_amd", "csrc", "libcor_amd.so"))
+
+
+def test_cpu_tensor_is_refused():
+    ops, _ = _ops()
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 16), torch.zeros(4, 16))
+
+
+# ======================================================================================================
+# GEMM
+# ======================================================================================================
+GEMM_SHAPES = [(128, 128, 128), (300, 200, 256), (1000, 768, 3072), (7, 1, 768), (64, 8, 256), (4096, 2304, 768),
+               (33, 130, 588), (2, 512, 16), (576, 256, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("T", [F32, BF16])
+def test_gemm_plain(M, N, K, T):
+    ops, _ = _ops()
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(T)
+    w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32)).to(T)
+    ref = a.float().double() @ w.float().double().T
+    out = ops.gemm(a.to(DEV), w.to(DEV), out_dtype=F32)
+    # inputs are identical (already rounded to T); products exact in fp32; only the summation order differs
+    report(f"gemm_plain_{M}x{N}x{K}_{T}", out, ref.float(), rtol=1e-5, atol=2e-5 * math.sqrt(K) * 4)
+
+
+@pytest.mark.parametrize("T,TO", [(F32, F32), (BF16, BF16), (BF16, F32)])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm_epilogue(T, TO, act):
+    ops, _ = _ops()
+    M, N, K = 260, 200, 192
+    rng = np.random.default_rng(act + 11)
+    a = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(T)
+    w = torch.from_numpy(rng.standard_normal((N, K), dtype=np.float32) / math.sqrt(K)).to(T)
+    bias = torch.from_numpy(rng.standard_normal(N, dtype=np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((52, N), dtype=np.float32))      # periodic residual (M = 5 * 52)
+    z = a.float() @ w.float().T + bias
+    actf = [lambda v: v, lambda v: torch.nn.functional.gelu(v), torch.relu, torch.sigmoid,
+            lambda v: torch.nn.functional.gelu(v, approximate="tanh")][act]
+    ref = actf(z) * scale + res.repeat(5, 1)
+    out = ops.gemm(a.to(DEV), w.to(DEV), out_dtype=TO, bias=bias.to(DEV), act=act, col_scale=scale.to(DEV),
+                   residual=res.to(DEV), res_row_mod=52)
+    tol = dict(rtol=1e-4, atol=1e-4) if TO == F32 else dict(rtol=1e-2, atol=1e-2)
+    report(f"gemm_epi_act{act}_{T}_{TO}", out, ref, **tol)
+
+
+def test_gemm_inplace_residual_and_strided_views():
+    ops, _ = _ops()
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((500, 256), dtype=np.float32)).to(DEV)
+    a = torch.from_numpy(rng.standard_normal((500, 1536), dtype=np.float32)).to(DEV)
+    w = torch.from_numpy(rng.standard_normal((256, 512), dtype=np.float32) / 16).to(DEV)
+    ref = x.cpu() + a.cpu()[:, 512:1024] @ w.cpu().T
+    ops.gemm(a[:, 512:1024], w, out_dtype=F32, residual=x, out=x)          # A is a column slice; C aliases the residual
+    report("gemm_inplace_strided", x, ref, rtol=1e-4, atol=1e-4)
+
+
+# ======================================================================================================
+# row kernels
+# ======================================================================================================
+@pytest.mark.parametrize("C", [4, 16, 64, 256, 768, 1024, 1152])
+@pytest.mark.parametrize("TI,TO", [(F32, F32), (F32, BF16), (BF16, F32)])
+def test_layernorm(C, TI, TO):
+    ops, _ = _ops()
+    rng = np.random.default_rng(C)
+    x = torch.from_numpy(rng.standard_normal((37, C), dtype=np.float32) * 3 + 1).to(TI)
+    w = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(C, dtype=np.float32))
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), w, b, 1e-6)
+    out = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, out_dtype=TO)
+    report(f"layernorm_C{C}_{TI}_{TO}", out, ref, **(dict(rtol=1e-4, atol=1e-4) if TO == F32 else dict(rtol=1e-2, atol=2e-2)))
+
+
+def test_small_row_ops():
+    ops, _ = _ops()
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((9, 768), dtype=np.float32))
+    report("l2norm", ops.l2norm_rows(x.to(DEV)), torch.nn.functional.normalize(x, dim=-1), 1e-5, 1e-6)
+    a = torch.from_numpy(rng.standard_normal((6, 64, 32), dtype=np.float32))
+    b = torch.from_numpy(rng.standard_normal((64, 32), dtype=np.float32))
+    report("add_periodic", ops.add(a.to(DEV), b.to(DEV)), a + b, 1e-6, 1e-6)
+    report("add_periodic_bf16", ops.add(a.to(DEV), b.to(DEV), out_dtype=BF16), (a + b).to(BF16), 1e-2, 1e-2)
+    report("cast_bf16", ops.cast(x.to(DEV), BF16), x.to(BF16), 0, 0)
+    t = ops.tokens_to_nchw(a.to(DEV), 6, 64, 32)
+    report("tokens_to_nchw", t, a.permute(0, 2, 1), 0, 0)
+    report("nchw_to_tokens", ops.nchw_to_tokens(t, F32).view(6, 64, 32), a, 0, 0)
+    ids = torch.from_numpy(rng.integers(0, 100, (3, 64)))
+    table = torch.from_numpy(rng.standard_normal((100, 32), dtype=np.float32))
+    pos = torch.from_numpy(rng.standard_normal((64, 32), dtype=np.float32))
+    report("embed_tokens", ops.embed_tokens(ids.to(DEV), table.to(DEV), pos.to(DEV)).view(3, 64, 32), table[ids] + pos, 0, 0)
+
+
+@pytest.mark.parametrize("p,size", [(16, 64), (14, 56)])
+@pytest.mark.parametrize("T", [F32, BF16])
+def test_patchify(p, size, T):
+    ops, _ = _ops()
+    rng = np.random.default_rng(p)
+    img = torch.from_numpy(rng.standard_normal((2, 3, size, size), dtype=np.float32))
+    K = 3 * p * p
+    Kp = (K + 15) // 16 * 16
+    g = size // p
+    ref = img.reshape(2, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(2 * g * g, K)
+    ref = torch.nn.functional.pad(ref, (0, Kp - K)).to(T)
+    report(f"patchify_p{p}_{T}", ops.patchify(img.to(DEV), p, Kp, T), ref, 0, 0)
+
+
+def test_im2col3x3():
+    ops, _ = _ops()
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.standard_normal((2, 8, 8, 16), dtype=np.float32))
+    cols = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), 3, padding=1)           # [B, C*9, HW], k = c*9 + tap
+    ref = cols.reshape(2, 16, 9, 64).permute(0, 3, 2, 1).reshape(128, 144)           # -> [B*HW, tap*C + c]
+    report("im2col3x3", ops.im2col3x3(x.to(DEV), 2, 8, 8), ref, 0, 0)
+
+
+# ======================================================================================================
+# attention
+# ======================================================================================================
+@pytest.mark.parametrize("hd,H,Tq,Tk", [(16, 8, 6, 4096), (16, 8, 4096, 6), (32, 8, 6, 6), (64, 12, 576, 576), (64, 12, 64, 64),
+                                         (72, 16, 100, 729), (64, 2, 200, 333)])
+@pytest.mark.parametrize("T", [F32, BF16])
+def test_attention_plain(hd, H, Tq, Tk, T):
+    ops, _ = _ops()
+    rng = np.random.default_rng(hd + Tq + Tk)
+    B, D = 2, H * hd
+    q = torch.from_numpy(rng.standard_normal((B * Tq, D), dtype=np.float32)).to(T)
+    kv = torch.from_numpy(rng.standard_normal((B * Tk, 2 * D), dtype=np.float32)).to(T)
+    scale = hd ** -0.5
+    sp = lambda t, Tn: t.float().reshape(B, Tn, H, hd).transpose(1, 2)
+    a = torch.softmax(sp(q, Tq) @ sp(kv[:, :D], Tk).transpose(2, 3) * scale, -1) @ sp(kv[:, D:], Tk)
+    ref = a.transpose(1, 2).reshape(B * Tq, D)
+    kvd = kv.to(DEV)
+    out = ops.attention(q.to(DEV), kvd[:, :D], kvd[:, D:], B, H, Tq, Tk, hd, scale, out_dtype=F32)
+    report(f"attention_hd{hd}_{Tq}x{Tk}_{T}", out, ref, **(dict(rtol=1e-4, atol=1e-4) if T == F32 else dict(rtol=2e-2, atol=2e-2)))
+
+
+@pytest.mark.parametrize("tag", ["win14", "glob16"])
+def test_sam_attention_vs_reference_golden(tag):
+    """qkv GEMM -> cor_sam_attention -> proj GEMM against lib/sam_model/image_encoder.py Attention (golden)."""
+    ops, engine = _ops()
+    g = load(f"sam_attention_{tag}")
+    S, dim, heads = int(g["S"]), int(g["dim"]), int(g["heads"])
+    cfg = dict(dim=dim, heads=heads, depth=1, global_idx=(0,), window=14, img=S * 16, patch=16, out=16)
+    spec = {k: v for k, v in ocfg.sam_encoder_spec(cfg, "e.").items() if k.startswith("e.blocks.0.attn.")}
+    sd = dev(ocfg.random_state(spec, int(g["seed_params"])))
+    x = make_inputs(int(g["seed_inputs"]), x=(3, S, S, dim))["x"].to(DEV).reshape(-1, dim)
+    p = "e.blocks.0.attn."
+    qkv = ops.gemm(x, sd[p + "qkv.weight"], bias=sd[p + "qkv.bias"])
+    a = ops.sam_attention(qkv, sd[p + "qkv.bias"], sd[p + "rel_pos_h"], sd[p + "rel_pos_w"], 3, heads, S, 0)
+    y = ops.gemm(a, sd[p + "proj.weight"], bias=sd[p + "proj.bias"])
+    report(f"sam_attention_golden_{tag}", y.view(3, S, S, dim), g["y"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("window", [14, 0])
+@pytest.mark.parametrize("T", [F32, BF16])
+def test_sam_attention_real_dims(window, T):
+    """hd 64, grid 64 (window 14 -> 5x5 padded windows; 0 -> global 4096 keys) against the oracle."""
+    ops, _ = _ops()
+    heads, dim, grid, B = 2, 128, 64, 1
+    cfg = dict(dim=dim, heads=heads, depth=1, global_idx=(0,) if window == 0 else (), window=14, img=1024, patch=16, out=16)
+    spec = {k: v for k, v in ocfg.sam_encoder_spec(cfg, "e.").items() if k.startswith("e.blocks.0.attn.")}
+    sd = ocfg.random_state(spec, 31)
+    p = "e.blocks.0.attn."
+    x = make_inputs(32, x=(B, grid, grid, dim))["x"]
+    if T == BF16:   # same rounded operands on both sides
+        x = x.to(BF16).float()
+        for k in (p + "qkv.weight", p + "proj.weight"):
+            sd[k] = sd[k].to(BF16).float()
+    if window:
+        xw, pad_hw = osam.to_windows(x, window)
+        ref = osam.from_windows(osam.vit_attention(sd, p, xw, heads), window, pad_hw, (grid, grid))
+    else:
+        ref = osam.vit_attention(sd, p, x, heads)
+    d = dev(sd)
+    xd = x.to(DEV).reshape(-1, dim).to(T)
+    qkv = ops.gemm(xd, d[p + "qkv.weight"].to(T), bias=d[p + "qkv.bias"])
+    a = ops.sam_attention(qkv, d[p + "qkv.bias"].to(T), d[p + "rel_pos_h"], d[p + "rel_pos_w"], B, heads, grid, window)
+    y = ops.gemm(a, d[p + "proj.weight"].to(T), out_dtype=F32, bias=d[p + "proj.bias"])
+    report(f"sam_attention_hd64_w{window}_{T}", y.view(B, grid, grid, dim), ref,
+           **(dict(rtol=1e-3, atol=2e-4) if T == F32 else dict(rtol=5e-2, atol=5e-2)))
+
+
+# ======================================================================================================
+# stages against REFERENCE golden vectors (fp32 exact mode)
+# ======================================================================================================
+@pytest.mark.parametrize("tag", ["img256", "img1024"])
+def test_sam_encoder_vs_reference_golden(tag):
+    _, engine = _ops()
+    g = load(f"sam_encoder_{tag}")
+    cfg = dict(dim=int(g["dim"]), heads=int(g["heads"]), depth=int(g["depth"]), global_idx=tuple(int(i) for i in g["global_idx"]),
+               window=14, img=int(g["img"]), patch=16, out=int(g["out"]))
+    pk = packer(ocfg.random_state(ocfg.sam_encoder_spec(cfg), int(g["seed_params"])), F32)
+    engine.pack_sam_encoder(pk, cfg)
+    B = int(g["B"])
+    x = make_inputs(int(g["seed_inputs"]), x=(B, 3, cfg["img"], cfg["img"]))["x"].to(DEV)
+    tok = engine.sam_encoder(pk.W, x, cfg, F32)
+    gr = cfg["img"] // 16
+    from cor_amd import ops
+    y = ops.tokens_to_nchw(tok, B, gr * gr, cfg["out"]).view(B, cfg["out"], gr, gr)
+    report(f"sam_encoder_golden_{tag}", y, g["y"], rtol=1e-3, atol=1e-3)
+
+
+def test_mask_decoder_vs_reference_golden():
+    ops, engine = _ops()
+    g = load("mask_decoder")
+    pk = packer(ocfg.random_state(dict(ocfg.mask_decoder_spec(), **ocfg.prompt_encoder_spec()), int(g["seed_params"])), F32)
+    engine.pack_mask_decoder(pk)
+    engine.pack_prompt_encoder(pk)
+    inp = make_inputs(int(g["seed_inputs"]), emb=(2, 256, 64, 64), sparse=(2, 1, 256))
+    pe = ops.tokens_to_nchw(pk.W["prompt.dense_pe"], 1, 4096, 256).view(1, 256, 64, 64)
+    report("dense_pe_golden", pe[..., ::4, ::4], g["dense_pe"], rtol=1e-4, atol=1e-4)
+    emb_tok = ops.nchw_to_tokens(inp["emb"].to(DEV), F32)
+    feat = inp["sparse"].to(DEV).reshape(2, 256).contiguous()
+    for mm in (0, 1):
+        final, iou, best, masks_all, keys = engine.mask_decoder(pk.W, emb_tok, feat, F32, bool(mm), all_masks=True)
+        sl = slice(1, None) if mm else slice(0, 1)
+        report(f"decoder_masks_golden_mm{mm}", masks_all[:, sl][..., ::4, ::4], g[f"masks_{mm}"], rtol=1e-3, atol=1e-3)
+        report(f"decoder_iou_golden_mm{mm}", iou[:, sl], g[f"iou_{mm}"], rtol=1e-3, atol=1e-3)
+        # the selected mask equals the argmax-IoU slice of the full set (sam_with_sup_branch.py:96-100)
+        ref_best = torch.from_numpy(g[f"iou_{mm}"]).argmax(1)
+        assert torch.equal(best.cpu(), ref_best), (best, ref_best)
+        k_off = 1 if mm else 0
+        pick = masks_all[torch.arange(2), k_off + best].unsqueeze(1)
+        report(f"decoder_final_is_selected_mm{mm}", final, pick, rtol=0, atol=0)
+    src = ops.tokens_to_nchw(keys, 2, 4096, 256).view(2, 256, 64, 64)
+    report("decoder_src_golden", src[..., ::4, ::4], g["src"], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("D,grid", [(768, 24), (1024, 24), (1152, 27)])
+def test_mask_adapter_vs_reference_golden(D, grid):
+    ops, engine = _ops()
+    g = load(f"mask_adapter_D{D}")
+    pk = packer(ocfg.random_state(ocfg.mask_adapter_spec(D, "mp."), int(g["seed_params"])), F32)
+    engine.pack_mask_adapter(pk, "mp.")
+    inp = make_inputs(int(g["seed_inputs"]), feat=(2, D, grid, grid), mask=("mask", 2, 384))
+    report(f"bilinear_golden_{grid}", ops.bilinear(inp["mask"].to(DEV), grid, grid), g["mask_small"], 1e-5, 1e-6)
+    feat_tok = ops.nchw_to_tokens(inp["feat"].to(DEV), F32)
+    pooled, maps = engine.mask_adapter_pooling(pk.W, feat_tok, inp["mask"].to(DEV), 2, grid, D, F32, "mp.")
+    report(f"adapter_maps_golden_D{D}", ops.tokens_to_nchw(maps, 2, grid * grid, 8).view(2, 8, grid, grid), g["maps"], 1e-3, 1e-3)
+    report(f"adapter_pooled_golden_D{D}", pooled.view(2, 1, D), g["y"], 1e-3, 1e-4)
+
+
+def test_masked_pooling_and_region_embedding_vs_reference_golden():
+    ops, _ = _ops()
+    g = load("masked_pooling")
+    inp = make_inputs(int(g["seed_inputs"]), feat=(2, 768, 24, 24), mask=("mask", 2, 384))
+    m = ops.bilinear(inp["mask"].to(DEV), 24, 24)
+    report("masked_pooling_golden", ops.masked_pool(ops.nchw_to_tokens(inp["feat"].to(DEV), F32), m, 2, 576, 768), g["y"], 1e-4, 1e-5)
+    g = load("region_embedding")
+    inp = make_inputs(int(g["seed_inputs"]), emb=(3, 256, 64, 64), mask=("mask", 3, 256), feat=(3, 1, 256))
+    from cor_amd import retrieval
+    r = retrieval.region_embedding(inp["emb"].to(DEV), inp["mask"].to(DEV))
+    report("region_embedding_golden", r, g["y"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("D", [768, 1024])
+def test_cir_fuse_vs_reference_golden(D):
+    ops, engine = _ops()
+    g = load(f"cir_fuse_D{D}")
+    pk = packer(ocfg.random_state(ocfg.fuse_spec(D, "f."), int(g["seed_params"])), F32)
+    engine.pack_fuse(pk, "f.")
+    inp = make_inputs(int(g["seed_inputs"]), img=(4, D), txt=(4, D))
+    img, txt = inp["img"].to(DEV), inp["txt"].to(DEV)
+    raw = torch.cat([img, txt], 1).contiguous()   # test-side plumbing only
+    gate = lambda n, x: ops.gemm(ops.gemm(x, pk.W[f"f.{n}.0.weight"], bias=pk.W[f"f.{n}.0.bias"], act=ops.ACT_RELU),
+                                 pk.W[f"f.{n}.3.weight"], bias=pk.W[f"f.{n}.3.bias"], act=ops.ACT_SIGMOID)
+    cat = ops.fuse_gate(img, txt, gate("atten_Image", raw), gate("atten_Text", raw))
+    dyn = gate("dynamic_scalar", cat)
+    report(f"cir_fuse_dyn_golden_D{D}", dyn, g["dyn"], 1e-3, 1e-4)
+    report(f"cir_fuse_golden_D{D}", ops.fuse_mix(cat, dyn), g["y"], 1e-3, 1e-5)
+
+
+# ======================================================================================================
+# whole model
+# ======================================================================================================
+def _build(sam_depth, gidx, gcfg, pooling):
+    from cor_amd.lib.sam_model.image_encoder import ImageEncoderViT
+    from cor_amd.lib.sam_model.mask_decoder import MaskDecoder
+    from cor_amd.lib.sam_model.my_prompt_encoder import PromptEncoder
+    from cor_amd.lib.sam_model.transformer import TwoWayTransformer
+    from cor_amd.lib.sam_with_sup_branch import CirSegModelWithQuerySupportFeat
+    from cor_amd.lib.support_branch import SupportBranch
+    return CirSegModelWithQuerySupportFeat(
+        image_encoder=ImageEncoderViT(embed_dim=768, depth=sam_depth, num_heads=12, global_attn_indexes=gidx),
+        support_branch=SupportBranch("ViT-B-16-SigLIP-384", None, pooling, siglip_cfg=gcfg),
+        prompt_encoder=PromptEncoder(256, (64, 64)),
+        mask_decoder=MaskDecoder(transformer_dim=256, transformer=TwoWayTransformer(2, 256, 8, 2048)))
+
+
+@pytest.mark.parametrize("pooling", ["MaskAdapterPooling", "MaskedPooling"])
+def test_full_forward_vs_reference_golden(pooling):
+    """SAM-B (all 12 blocks) + 2-block SigLIP stand-in: the golden outputs come from the reference's own
+    build_model_with_query_support_feat(...).forward (tools/make_golden.py gen_toplevel). fp32 exact mode."""
+    from cor_amd import config
+    g = load(f"toplevel_{pooling}")
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=2, t_depth=2, vocab=512)
+    model = _build(12, (2, 5, 8, 11), gcfg, pooling)
+    # the stand-in used for the golden run has no MAP head
+    spec = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = ocfg.random_state({k: v for k, v in spec.items() if "attn_pool" not in k}, int(g["seed_params"]))
+    missing = model.load_state_dict(sd, strict=False)
+    assert all("attn_pool" in k for k in missing.missing_keys) and not missing.unexpected_keys
+    assert sorted(sd) == [str(k) for k in g["keys"]]
+    model = model.to(DEV).eval()
+    inp = make_inputs(int(g["seed_inputs"]), q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 512), mask=("mask", 1, 384))
+    kw = dict(query_image_inputs=inp["q"].to(DEV), support_image_inputs=inp["s"].to(DEV), change_text_inputs=inp["text"].to(DEV),
+              support_mask_inputs=inp["mask"].to(DEV))
+    for mm in (1, 0):
+        masks, emb, feat = model(**kw, multimask_output=bool(mm))
+        assert masks.shape == (1, 1, 256, 256) and emb.shape == (1, 256, 64, 64) and feat.shape == (1, 1, 256)
+        report(f"full_masks_golden_{pooling}_mm{mm}", masks[..., ::4, ::4], g[f"masks_{mm}"], rtol=1e-3, atol=2e-3)
+    report(f"full_emb_golden_{pooling}", emb[..., ::4, ::4], g["emb"], rtol=1e-3, atol=1e-3)
+    report(f"full_feat_golden_{pooling}", feat, g["feat"], rtol=1e-3, atol=1e-4)
+    # mask "argmax" parity = the >0 threshold of the logits (mask_threshold 0.0) on the sub-sampled golden
+    agree = ((masks[..., ::4, ::4].cpu() > 0) == (torch.from_numpy(g["masks_0"]) > 0)).float().mean().item()
+    assert agree == 1.0, f"mask threshold disagreement: {1 - agree:.2e}"
+
+
+def test_full_forward_bf16_mode_vs_oracle():
+    """bf16 fast mode (what the reference runs under accelerator.autocast): budget = 3e-2 of the output scale on the
+    embeddings / support feature, mask sign agreement >= 99 %. B=2 exercises batching."""
+    from cor_amd import config
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=2, t_depth=2, vocab=512)
+    model = _build(2, (1,), gcfg, "MaskAdapterPooling")
+    sd = ocfg.random_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 41)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    inp = make_inputs(42, q=(2, 3, 1024, 1024), s=(2, 3, 384, 384), text=("tokens", 2, 64, 512), mask=("mask", 2, 384))
+    scfg = dict(model.image_encoder.cfg)
+    ref_emb = osam.image_encoder(sd, inp["q"], scfg)
+    ref_feat = osup.support_branch(sd, inp["s"], inp["text"], inp["mask"], gcfg, "MaskAdapterPooling")
+    ref_masks, ref_iou, _ = osam.mask_decoder(sd, ref_emb, osam.dense_pe(sd), ref_feat, osam.dense_no_mask(sd, 2), True)
+    kw = dict(query_image_inputs=inp["q"].to(DEV), support_image_inputs=inp["s"].to(DEV), change_text_inputs=inp["text"].to(DEV),
+              support_mask_inputs=inp["mask"].to(DEV))
+    # fp32 exact mode, B=2
+    masks, emb, feat, aux = model.forward_with_aux(**kw, multimask_output=True)
+    report("full_fp32_emb_vs_oracle", emb, ref_emb, 1e-3, 2e-3)
+    report("full_fp32_feat_vs_oracle", feat, ref_feat, 1e-3, 1e-4)
+    report("full_fp32_masks_vs_oracle", aux["masks"][:, 1:], ref_masks, 2e-3, 5e-3)
+    assert torch.equal(aux["best"].cpu(), ref_iou.argmax(1))
+    # bf16 mode through autocast, like the reference's inference harness (vailder.py:416)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        masks_b, emb_b, feat_b = model(**kw, multimask_output=True)
+    es = ref_emb.abs().max().item()
+    report("full_bf16_emb_vs_oracle", emb_b, ref_emb, 0, 3e-2 * es)
+    report("full_bf16_feat_vs_oracle", feat_b, ref_feat, 0, 3e-2)
+    ref_final = ref_masks[torch.arange(2), ref_iou.argmax(1)].unsqueeze(1)
+    agree = ((masks_b.cpu() > 0) == (ref_final > 0)).float().mean().item()
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(dict(name="full_bf16_mask_sign_agreement", value=agree)) + "\n")
+    assert agree >= 0.99, agree
+
+
+def test_siglip_towers_vs_oracle():
+    _, engine = _ops()
+    from cor_amd import config
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=2, t_depth=2, vocab=512)
+    spec = ocfg.siglip_spec(gcfg, with_map_head=False)
+    sd = ocfg.random_state(spec, 51)
+    pk = packer(sd, F32)
+    engine.pack_siglip(pk, gcfg)
+    inp = make_inputs(52, s=(2, 3, 384, 384), text=("tokens", 2, 64, 512))
+    vis = engine.siglip_vision(pk.W, inp["s"].to(DEV), gcfg, F32)
+    report("siglip_vision_vs_oracle", vis.view(2, 576, 768), osig.vision_tokens(sd, inp["s"], gcfg), 1e-3, 1e-3)
+    txt = engine.siglip_text(pk.W, inp["text"].to(DEV), gcfg, F32)
+    report("siglip_text_vs_oracle", txt, osig.text_features(sd, inp["text"], gcfg), 1e-3, 1e-4)
+
+
+# ======================================================================================================
+# retrieval
+# ======================================================================================================
+@pytest.mark.parametrize("Bq,Ng,k", [(4, 1000, 5), (32, 10000, 10), (7, 37, 32), (64, 4097, 1)])
+@pytest.mark.parametrize("gdt", [F32, BF16, torch.float16])
+def test_similarity_topk(Bq, Ng, k, gdt):
+    ops, _ = _ops()
+    rng = np.random.default_rng(Bq + Ng)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Bq, 256), dtype=np.float32)), dim=-1)
+    G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Ng, 256), dtype=np.float32)), dim=-1).to(gdt)
+    G[5] = G[3]                                   # exact duplicate rows: ties must resolve to the smaller index
+    s, i = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, g_offset=1000)
+    Qr = Q if gdt == F32 else Q.to(gdt).float()
+    rs, ri = oret.similarity_topk(Qr, G.float(), k)
+    kk = min(k, Ng)
+    report(f"topk_scores_{Bq}x{Ng}_k{k}_{gdt}", s[:, :kk], rs, 1e-5, 2e-6)
+    # indices: identical wherever the oracle's neighbouring scores are separated by more than fp32 summation noise
+    gap_ok = torch.ones_like(ri, dtype=torch.bool)
+    full = torch.sort(Qr @ G.float().T, dim=1, descending=True).values
+    for j in range(kk):
+        lo = full[:, j] - full[:, j + 1] if j + 1 < Ng else torch.ones(Bq)
+        hi = full[:, j - 1] - full[:, j] if j > 0 else torch.ones(Bq)
+        gap_ok[:, j] = (lo > 1e-6) & (hi > 1e-6)
+    same = (i[:, :kk].cpu() - 1000 == ri) | ~gap_ok
+    assert same.all(), f"top-k index mismatch at {(~same).nonzero()[:5]}"
+    if k > Ng:
+        assert (i[:, Ng:] == -1).all() and torch.isinf(s[:, Ng:]).all()
