@@ -45,7 +45,8 @@ def cpu_baseline(args):
     same workload + similarity vs the same gallery size. kind = "port"."""
     from oracle import config as ocfg, model as omodel, retrieval as oret
     from tests.golden_util import make_inputs
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives one GPU's share of the host: 16 cores
+    torch.set_num_threads(ncores)
     spec = ocfg.model_spec(args.sam, args.siglip, "MaskAdapterPooling")
     sd = ocfg.random_state(spec, seed=0)
     inp = make_inputs(1, q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 32000), mask=("mask", 1, 384))
