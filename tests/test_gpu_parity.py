@@ -204,6 +204,27 @@ def test_attention_plain(hd, H, Tq, Tk, T):
     report(f"attention_hd{hd}_{Tq}x{Tk}_{T}", out, ref, **(dict(rtol=1e-4, atol=1e-4) if T == F32 else dict(rtol=2e-2, atol=2e-2)))
 
 
+@pytest.mark.parametrize("T", [F32, BF16])
+def test_attention_online_softmax_rescale(T):
+    """Forces the running-max rescale: a few keys late in the sequence dominate some queries (logit spikes of +30..60
+    planted at chosen tiles), so the accumulator must be rescaled after many tiles were already summed."""
+    ops, _ = _ops()
+    rng = np.random.default_rng(77)
+    B, H, hd, Tq, Tk = 1, 2, 64, 256, 640
+    D = H * hd
+    q = torch.from_numpy(rng.standard_normal((B * Tq, D), dtype=np.float32))
+    k = torch.from_numpy(rng.standard_normal((B * Tk, D), dtype=np.float32))
+    v = torch.from_numpy(rng.standard_normal((B * Tk, D), dtype=np.float32))
+    for qi, ki, gain in ((3, 70, 6.0), (100, 333, 8.0), (255, 639, 10.0), (17, 5, 7.0), (64, 575, 9.0)):
+        k[ki, :hd] = q[qi, :hd] * gain / 8.0          # q.k/sqrt(64) ~ gain * |q|^2 / 64 ~ gain * 8
+        k[ki, hd:] = q[qi, hd:] * gain / 8.0
+    q, k, v = q.to(T), k.to(T), v.to(T)
+    sp = lambda t, Tn: t.float().reshape(B, Tn, H, hd).transpose(1, 2)
+    ref = (torch.softmax(sp(q, Tq) @ sp(k, Tk).transpose(2, 3) * hd ** -0.5, -1) @ sp(v, Tk)).transpose(1, 2).reshape(B * Tq, D)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, H, Tq, Tk, hd, hd ** -0.5, out_dtype=F32)
+    report(f"attention_rescale_{T}", out, ref, **(dict(rtol=1e-4, atol=1e-4) if T == F32 else dict(rtol=2e-2, atol=2e-2)))
+
+
 @pytest.mark.parametrize("tag", ["win14", "glob16"])
 def test_sam_attention_vs_reference_golden(tag):
     """qkv GEMM -> cor_sam_attention -> proj GEMM against lib/sam_model/image_encoder.py Attention (golden)."""
