@@ -21,6 +21,7 @@ _p, _i, _l, _f, _ll = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_longlong
 SIGNATURES = {
     "cor_version": [],
     "cor_gemm": [_p, _l, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _i, _p, _p, _l, _i, _p],
+    "cor_gemm_set_config": [_i],
     "cor_layernorm": [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p],
     "cor_attention": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p, _l, _l, _i, _i, _i, _i, _i, _i, _f, _p],
     "cor_sam_attention": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],

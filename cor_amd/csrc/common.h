@@ -49,7 +49,19 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
   *(uint2*)p = u;
 }
 
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off level), ~15 VALU ops instead of libm's ~40:
+// the GELU epilogue of the MLP GEMMs runs once per output element.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
 }

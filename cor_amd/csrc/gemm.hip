@@ -17,6 +17,10 @@
 //   * XCD-aware tile order: blocks that share an XCD walk N-tiles of the same A row-panel (L2 reuse of A).
 #include "common.h"
 
+#ifndef COR_GEMM_DEFAULT_BIG
+#define COR_GEMM_DEFAULT_BIG 2
+#endif
+
 namespace {
 
 struct GemmArgs {
@@ -27,6 +31,7 @@ struct GemmArgs {
   int tm, tn;
   const float* bias; const float* col_scale; const float* residual;
   long ldr; int res_row_mod; int act;
+  int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
 };
 
 template <typename TA> struct Mfma;
@@ -44,96 +49,198 @@ template <> struct Mfma<bf16_t> {
   }
 };
 
-constexpr int BM = 128, BN = 128, ROWB = 128;          // tile rows / bytes of K per row per step
-constexpr int TILE_BYTES = BM * ROWB;                  // 16 KiB per operand per buffer
-constexpr int GEMM_LDS = 4 * TILE_BYTES;               // A0 B0 A1 B1 = 64 KiB
+constexpr int ROWB = 128;                              // bytes of K per tile row per K-step
 
-template <typename TA, typename TO>
-__global__ void __launch_bounds__(256, 2) gemm_nt_mfma(const GemmArgs g) {
+// global -> LDS direct copy of 16 B per lane: LDS destination = lds_dst (wave-uniform, in M0) + lane*16.
+// M0 is compiler-reserved, so it is saved, set, used and restored inside ONE asm statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Tile-parametrised kernel. BM x BN block tile, WM x WN waves (each (BM/WM) x (BN/WN) = MI x NJ MFMA 32x32 tiles).
+// GLDS = true : operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write); the LDS
+//               image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE chunk and undone on the read;
+//               needs K bytes % 128 == 0.
+// GLDS = false: register-staged double buffering (handles a ragged K tail by zero fill).
+template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS>
+__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {   // <= 256 VGPR+AGPR: 2 waves per SIMD
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NJ = WTN / 32;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, BUF = A_BYTES + B_BYTES;
+  constexpr int ACH = BM * 8 / NT, BCH = BN * 8 / NT;   // 16-B chunks per thread per operand tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (swz / g.tn) * BM, n0 = (swz % g.tn) * BN;
 
-  // ---- staging map: thread handles chunk (tid + 256 i), i = 0..3, of each operand tile
-  const char* a_src[4]; const char* b_src[4]; int lds_st[4]; int kofs[4];
+  // ---- staging map: thread owns LDS chunk slots c = tid + NT*i (linear image: slot c lives at byte 16*c);
+  //      slot (row, sl) holds source chunk sl ^ ((row>>1)&7) of that row
+  const char* a_src[ACH]; const char* b_src[BCH]; int a_ko[ACH], b_ko[BCH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-    const int ar = min(m0 + row, g.M - 1), br = min(n0 + row, g.N - 1);   // clamp: rows past the edge are never stored
-    a_src[i] = g.A + (long)ar * g.lda_b + ch * 16;
-    b_src[i] = g.W + (long)br * g.ldw_b + ch * 16;
-    lds_st[i] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
-    kofs[i] = ch * 16;
+  for (int i = 0; i < ACH; ++i) {
+    const int c = tid + NT * i, row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
+    a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda_b + ch * 16;   // clamp: rows past the edge are never stored
+    a_ko[i] = ch * 16;
   }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int c = tid + NT * i, row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
+    b_src[i] = g.W + (long)min(n0 + row, g.N - 1) * g.ldw_b + ch * 16;
+    b_ko[i] = ch * 16;
+  }
+  const unsigned wslot = __builtin_amdgcn_readfirstlane(tid & ~63) * 16;  // this wave's first chunk slot (bytes)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+
   // ---- fragment read map
   const int r = lane & 31, h = lane >> 5, sw = (lane >> 1) & 7;
-  const int a_rd = (wm * 64 + r) * ROWB, b_rd = (wn * 64 + r) * ROWB;
+  const int a_rd = (wm * WTM + r) * ROWB, b_rd = A_BYTES + (wn * WTN + r) * ROWB;
   int ch_rd[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) ch_rd[s] = ((2 * s + h) ^ sw) << 4;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   const int nkt = (g.Kb + ROWB - 1) / ROWB;
-  uint4 ra[4], rb[4];
-  auto gload = [&](int kt) {
+  uint4 ra[GLDS ? 1 : ACH], rb[GLDS ? 1 : BCH];
+
+  auto stage_issue = [&](int kt, int buf) {          // GLDS: whole copy; REG: global -> registers
     const int kb = kt * ROWB;
+    if constexpr (GLDS) {
+      const unsigned base = lds0 + buf * BUF + wslot;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = kb + kofs[i] + 16 <= g.Kb;       // K tail: zero fill (K bytes is a multiple of 16)
-      ra[i] = ok ? *(const uint4*)(a_src[i] + kb) : make_uint4(0, 0, 0, 0);
-      rb[i] = ok ? *(const uint4*)(b_src[i] + kb) : make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < ACH; ++i) glds16(a_src[i] + kb, base + NT * 16 * i);
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) glds16(b_src[i] + kb, base + A_BYTES + NT * 16 * i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < ACH; ++i)
+        ra[i] = (kb + a_ko[i] + 16 <= g.Kb) ? *(const uint4*)(a_src[i] + kb) : make_uint4(0, 0, 0, 0);   // K tail: zero fill
+#pragma unroll
+      for (int i = 0; i < BCH; ++i)
+        rb[i] = (kb + b_ko[i] + 16 <= g.Kb) ? *(const uint4*)(b_src[i] + kb) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto lstore = [&](int buf) {
-    char* As = smem + buf * 2 * TILE_BYTES; char* Bs = As + TILE_BYTES;
+  auto stage_commit = [&](int buf) {                 // REG: registers -> LDS (linear, conflict-free)
+    if constexpr (!GLDS) {
+      char* base = smem + buf * BUF + tid * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { *(uint4*)(As + lds_st[i]) = ra[i]; *(uint4*)(Bs + lds_st[i]) = rb[i]; }
+      for (int i = 0; i < ACH; ++i) *(uint4*)(base + NT * 16 * i) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) *(uint4*)(base + A_BYTES + NT * 16 * i) = rb[i];
+    }
   };
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bool more = kt + 1 < nkt;
-    if (more) gload(kt + 1);
-    const char* As = smem + (kt & 1) * 2 * TILE_BYTES; const char* Bs = As + TILE_BYTES;
+  auto compute = [&](const char* buf) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const uint4 a0 = *(const uint4*)(As + a_rd + ch_rd[s]);
-      const uint4 a1 = *(const uint4*)(As + a_rd + 32 * ROWB + ch_rd[s]);
-      const uint4 b0 = *(const uint4*)(Bs + b_rd + ch_rd[s]);
-      const uint4 b1 = *(const uint4*)(Bs + b_rd + 32 * ROWB + ch_rd[s]);
-      Mfma<TA>::run(a0, b0, acc[0][0]);
-      Mfma<TA>::run(a0, b1, acc[0][1]);
-      Mfma<TA>::run(a1, b0, acc[1][0]);
-      Mfma<TA>::run(a1, b1, acc[1][1]);
+      uint4 af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const uint4*)(buf + a_rd + i * 32 * ROWB + ch_rd[s]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = *(const uint4*)(buf + b_rd + j * 32 * ROWB + ch_rd[s]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Mfma<TA>::run(af[i], bf[j], acc[i][j]);
     }
-    if (more) lstore((kt + 1) & 1);
+  };
+
+  // The LDS-DMA is issued from inline asm: hipcc fences every ds_read behind a pending builtin global_load_lds
+  // (s_waitcnt vmcnt(0) right after the issue, which serialises copy and MFMA). From asm the copy of tile t+1 stays
+  // in flight under the MFMAs of tile t; each wave drains its own DMA (vmcnt(0)) just before the barrier that
+  // publishes the buffer.
+  auto dma_wait = [&]() { if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  stage_issue(0, 0);
+  stage_commit(0);
+  dma_wait();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 1 < nkt) stage_issue(kt + 1, 1);
+    compute(smem);
+    if (kt + 1 < nkt) stage_commit(1);
+    dma_wait();
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    if (kt + 2 < nkt) stage_issue(kt + 2, 0);
+    compute(smem + BUF);
+    if (kt + 2 < nkt) stage_commit(0);
+    dma_wait();
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane owns
+  // one column, so direct stores are 2-4 B per lane (measured: ~1 TB/s). Instead each wave transposes 32-row slabs of its
+  // tile through LDS (the K-loop buffers are free now) and every lane then handles 4 CONSECUTIVE columns of one row:
+  // 16-B bias/residual loads, 16-B (fp32) or 8-B (bf16) stores, whole 128/256-B row segments per 16 lanes.
   TO* C = (TO*)g.C;
+  if (g.vec_epi) {
+    float* stg = (float*)smem + wave * (32 * WTN);
+    constexpr int VW = sizeof(TO) == 2 ? 8 : 4;       // columns per lane: one 16-B store either way
+    constexpr int CV = WTN / VW;                      // lanes per staged row
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
-    const int n = n0 + wn * 64 + nj * 32 + r;
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * h) * WTN + nj * 32 + r] = acc[mi][nj][e];
+#pragma unroll
+      for (int j = 0; j < (32 * CV) / 64; ++j) {
+        const int idx = j * 64 + lane, row = idx / CV, cv = idx - row * CV;
+        const int m = m0 + wm * WTM + mi * 32 + row, n = n0 + wn * WTN + cv * VW;
+        f32x4 v[VW / 4];
+#pragma unroll
+        for (int q4 = 0; q4 < VW / 4; ++q4) v[q4] = *(const f32x4*)(stg + row * WTN + cv * VW + 4 * q4);
+        if (m < g.M && n < g.N) {
+          const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
+#pragma unroll
+          for (int q4 = 0; q4 < VW / 4; ++q4) {
+            const int nn = n + 4 * q4;
+            if (nn < g.N) {                           // N % 4 == 0: a group of 4 is all-in or all-out
+              if (g.bias) v[q4] += *(const f32x4*)(g.bias + nn);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q4][q] = apply_act(v[q4][q], g.act);
+              if (g.col_scale) v[q4] *= *(const f32x4*)(g.col_scale + nn);
+              if (g.residual) v[q4] += *(const f32x4*)(g.residual + (long)rr * g.ldr + nn);
+            }
+          }
+          TO* cp = C + (long)m * g.ldc + n;
+          if constexpr (VW == 8) {
+            if (n + 8 <= g.N) {
+              uint4 u;
+              u.x = (uint32_t)f2bf(v[0][0]) | ((uint32_t)f2bf(v[0][1]) << 16); u.y = (uint32_t)f2bf(v[0][2]) | ((uint32_t)f2bf(v[0][3]) << 16);
+              u.z = (uint32_t)f2bf(v[1][0]) | ((uint32_t)f2bf(v[1][1]) << 16); u.w = (uint32_t)f2bf(v[1][2]) | ((uint32_t)f2bf(v[1][3]) << 16);
+              *(uint4*)cp = u;
+            } else {
+              st4<TO>(cp, v[0]);
+            }
+          } else {
+            st4<TO>(cp, v[0]);
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    const int n = n0 + wn * WTN + nj * 32 + r;
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.0f;
     const float sc = g.col_scale ? g.col_scale[n] : 1.0f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m >= g.M) continue;
         float v = apply_act(acc[mi][nj][e] + bv, g.act) * sc;
         if (g.residual) {
@@ -186,6 +293,22 @@ __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, cons
   }
 }
 
+int g_gemm_cfg = 0;   // 0 = auto; 1..6 force a tile configuration (tools/gemm_bench.py)
+
+template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS>
+int launch_tile(GemmArgs g, hipStream_t s) {
+  constexpr int LDS = 2 * (BM + BN) * ROWB;
+  g.tm = cdiv(g.M, BM); g.tn = cdiv(g.N, BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tile<TA, TO, BM, BN, WM, WN, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tile<TA, TO, BM, BN, WM, WN, GLDS>), dim3(g.tm * g.tn), dim3(WM * WN * 64), LDS, s, g);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename TA, typename TO>
 int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                 const float* bias, int act, const float* col_scale, const float* residual, long ldr, int res_row_mod,
@@ -193,28 +316,41 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   const long esz = sizeof(TA);
   const bool fast = (K * esz) % 16 == 0 && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0 &&
                     ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0);
-  if (fast) {
-    GemmArgs g;
-    g.A = (const char*)A; g.W = (const char*)W; g.C = (char*)C;
-    g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
-    g.M = M; g.N = N; g.Kb = (int)(K * esz);
-    g.tm = cdiv(M, BM); g.tn = cdiv(N, BN);
-    g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_mfma<TA, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_mfma<TA, TO>), dim3(g.tm * g.tn), dim3(256), GEMM_LDS, s, g);
-  } else {
+  if (!fast) {
     hipLaunchKernelGGL((gemm_nt_small<TA, TO>), dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, s, (const TA*)A, lda,
                        (const TA*)W, ldw, (TO*)C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod);
+    COR_CHECK_LAUNCH();
+    return 0;
   }
-  COR_CHECK_LAUNCH();
-  return 0;
+  GemmArgs g;
+  g.A = (const char*)A; g.W = (const char*)W; g.C = (char*)C;
+  g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
+  g.M = M; g.N = N; g.Kb = (int)(K * esz);
+  g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
+  const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  g.vec_epi = (N % 4 == 0) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
+              (!residual || (al16(residual) && ldr % 4 == 0));
+  const bool k128 = g.Kb % ROWB == 0;                 // direct-to-LDS staging cannot zero-fill a K tail
+  int cfg = g_gemm_cfg;
+  if (cfg == 0) cfg = (k128 && M >= 512 && N >= 64) ? COR_GEMM_DEFAULT_BIG : 1;
+  if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
+  switch (cfg) {
+    case 2: return launch_tile<TA, TO, 128, 128, 2, 2, true>(g, s);
+    case 3: return launch_tile<TA, TO, 256, 128, 4, 2, true>(g, s);
+    case 4: return launch_tile<TA, TO, 256, 256, 2, 4, true>(g, s);
+    case 5: return launch_tile<TA, TO, 256, 128, 4, 2, false>(g, s);
+    case 6: return launch_tile<TA, TO, 256, 256, 2, 4, false>(g, s);
+    default: return launch_tile<TA, TO, 128, 128, 2, 2, false>(g, s);
+  }
 }
 
 }  // namespace
+
+extern "C" int cor_gemm_set_config(int cfg) {
+  if (cfg < 0 || cfg > 6) return COR_EINVAL;
+  g_gemm_cfg = cfg;
+  return 0;
+}
 
 extern "C" int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype, void* C, long ldc, int c_dtype,
                         int M, int N, int K, const float* bias, int act, const float* col_scale,

@@ -42,6 +42,10 @@ int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype,
              const float* bias, int act, const float* col_scale,
              const float* residual, long ldr, int res_row_mod, void* stream);
 
+/* Tuning knob for tools/gemm_bench.py: 0 = automatic tile choice (default), 1..6 force one tile configuration
+ * (1: 128x128 reg-staged, 2: 128x128 direct-to-LDS, 3/5: 256x128 LDS-DMA/reg, 4/6: 256x256 LDS-DMA/reg). */
+int cor_gemm_set_config(int cfg);
+
 /* y[r,:] = LayerNorm(x[r,:]) * w + b over the last dim, biased variance.
  * ref: nn.LayerNorm (image_encoder.py:169,183), LayerNorm2d common.py:31-43 and mask_adapter.py:226-251 (on
  *      channels-last rows), transformer.py norm1..4. */

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark of cor_gemm tile configurations (cor_gemm_set_config) on the SAM-B / SigLIP-B shapes.
+Interleaved rounds in ONE process, random data (cdna guide rules 24/25). Checks every configuration against
+configuration 1 bit-for-bit tolerance-free on a sub-block (same accumulation order per k-step => tiny diffs only).
+    python tools/gemm_bench.py [--cfgs 1 2 3 4 5 6] [--rounds 5]
+"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from cor_amd import ops, _native
+
+SHAPES = [  # (M, N, K, act, residual, out_f32, label)
+    (131072, 2304, 768, 0, False, False, "sam qkv"),
+    (131072, 768, 768, 0, True, True, "sam proj+res"),
+    (131072, 3072, 768, 1, False, False, "sam lin1+gelu"),
+    (131072, 768, 3072, 0, True, True, "sam lin2+res"),
+    (18432, 2304, 768, 0, False, False, "siglip qkv"),
+    (18432, 3072, 768, 1, False, False, "siglip fc1+gelu"),
+    (131072, 256, 2304, 0, False, True, "neck 3x3"),
+]
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfgs", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    T = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    lib = _native.load()
+    dev = "cuda:0"
+    res = []
+    for (M, N, K, act, use_res, of32, label) in SHAPES:
+        g = torch.Generator(device=dev).manual_seed(M + N + K)
+        A = torch.randn((M, K), generator=g, device=dev).to(T)
+        W = (torch.randn((N, K), generator=g, device=dev) / K ** 0.5).to(T)
+        bias = torch.randn((N,), generator=g, device=dev)
+        R = torch.randn((M, N), generator=g, device=dev) if use_res else None
+        od = torch.float32 if of32 else T
+        outs, times = {}, {c: [] for c in a.cfgs}
+        for c in a.cfgs:                                    # correctness + warm-up
+            _native.check(lib.cor_gemm_set_config(c), "set_config")
+            outs[c] = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R)[:512].float().clone()
+        torch.cuda.synchronize()
+        ref = outs[a.cfgs[0]]
+        errs = {c: float((outs[c] - ref).abs().max()) for c in a.cfgs}
+        tref = torch.nn.functional.linear(A[:512].float(), W.float(), bias)
+        if act == 1: tref = torch.nn.functional.gelu(tref)
+        if use_res: tref = tref + R[:512]
+        err_ref = float((ref - tref).abs().max())
+        for _ in range(a.rounds):
+            for c in a.cfgs:
+                lib.cor_gemm_set_config(c)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R)
+                e1.record(); e1.synchronize()
+                times[c].append(e0.elapsed_time(e1))
+        fl = 2.0 * M * N * K
+        row = dict(shape=f"{M}x{N}x{K}", label=label, err_vs_torch=err_ref,
+                   **{f"cfg{c}": dict(tf_med=fl / (sorted(times[c])[len(times[c]) // 2] * 1e-3) / 1e12,
+                                      tf_best=fl / (min(times[c]) * 1e-3) / 1e12, diff_vs_first=errs[c]) for c in a.cfgs})
+        print(json.dumps(row), flush=True)
+        res.append(row)
+    lib.cor_gemm_set_config(0)
+
+if __name__ == "__main__":
+    main()
