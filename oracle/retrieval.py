@@ -29,24 +29,24 @@ def cosine(a, b):
 
 
 def scores_fma_chain(Q, G):
-    """S[b,g] = fma(q[255],g[255], ... fma(q[1],g[1], fma(q[0],g[0], 0))) in fp32: the exact arithmetic of the
-    gfx950 f32 MFMA (k-ordered fmaf chain, one rounding per step), so GPU fp32 scores can be compared BITWISE.
-    Products of two fp32 are exact in fp64 and one fp64->fp32 rounding of (acc + prod) equals fmaf because
-    acc+prod is computed exactly enough: |acc|,|prod| fp32 => acc+prod needs <= 24+24+... bits; we use the
-    safe route: numpy float64 add then cast is NOT always identical to fmaf (double rounding), so do it with
-    integer-exact math via math.fma when available, else fall back to the float64 route and flag it."""
+    """fp32 scores by the exact k-ordered fmaf chain of the GPU's f32 MFMA (oracle/c/sim_chain.c, built by
+    __graft_entry__.build() into oracle/_build/libsimchain.so): bitwise comparable with cor_similarity_topk on an
+    fp32 gallery. Q [Bq,C], G [Ng,C] float32 numpy arrays, C % 8 == 0."""
+    import ctypes
+    import os
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libsimchain.so")
+    if not os.path.exists(so):
+        raise RuntimeError("oracle/_build/libsimchain.so missing: run python -c 'import __graft_entry__ as g; g.build()'")
+    lib = ctypes.CDLL(so)
     Q = np.ascontiguousarray(Q, dtype=np.float32)
     G = np.ascontiguousarray(G, dtype=np.float32)
-    acc = np.zeros((Q.shape[0], G.shape[0]), dtype=np.float32)
-    # float64 product of two float32 is exact (48-bit significand); acc (24 bit) + prod (48 bit) in float64
-    # (53 bit) is exact unless exponents differ by > 5 bits worth of slack; double rounding can then differ
-    # from a true fma in the last place in rare cases. Those cases are detected and fixed with exact
-    # rational arithmetic below.
-    for k in range(Q.shape[1]):
-        prod = Q[:, k:k + 1].astype(np.float64) * G[None, :, k].astype(np.float64)
-        s = acc.astype(np.float64) + prod
-        acc = s.astype(np.float32)
-    return acc
+    assert Q.shape[1] == G.shape[1] and Q.shape[1] % 8 == 0
+    out = np.empty((Q.shape[0], G.shape[0]), dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.sim_chain_scores.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
+    lib.sim_chain_scores.restype = None
+    lib.sim_chain_scores(Q.ctypes.data_as(fp), G.ctypes.data_as(fp), Q.shape[0], G.shape[0], Q.shape[1], out.ctypes.data_as(fp))
+    return out
 
 
 def similarity_topk(Q, G, k, exact_chain=False):

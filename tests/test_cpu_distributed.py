@@ -1,0 +1,71 @@
+"""world_size-2 gloo test (CPU, runs under -m "not gpu") of the multi-rank retrieval path: query all-gather,
+per-shard scoring, result gather and host merge (cor_amd.retrieval.distributed_search). The HIP scoring kernel
+needs a GPU, so each rank's shard is a test double whose .search() is the CPU oracle; everything else is the
+product's code."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _OracleShard:
+    def __init__(self, rows, offset):
+        self.rows, self.offset = rows, offset
+
+    def search(self, queries, k):
+        from oracle import retrieval as oret
+        s, i = oret.similarity_topk(queries, self.rows, k)
+        i = i + self.offset
+        if s.shape[1] < k:       # pad like the kernel does (score -inf, index -1)
+            pad = k - s.shape[1]
+            s = torch.cat([s, torch.full((s.shape[0], pad), float("-inf"))], 1)
+            i = torch.cat([i, torch.full((i.shape[0], pad), -1, dtype=torch.int64)], 1)
+        return s, i
+
+
+def _worker(rank, world, port, G, Q_all, k, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cor_amd import retrieval
+        lo, hi = retrieval.shard_bounds(G.shape[0], world, rank)
+        shard = _OracleShard(G[lo:hi], lo)
+        per = Q_all.shape[0] // world
+        s, i = retrieval.distributed_search(Q_all[rank * per:(rank + 1) * per], shard, k)
+        if rank == 0:
+            out["s"], out["i"] = s, i
+        # every rank must hold the same merged answer
+        ref = [None]
+        if rank == 0:
+            ref = [(s, i)]
+        dist.broadcast_object_list(ref, src=0)
+        assert torch.equal(ref[0][1], i) and torch.equal(ref[0][0], s)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("Ng,k", [(1000, 10), (7, 8)])
+def test_distributed_search_world2_gloo(Ng, k):
+    from oracle import retrieval as oret
+    gen = torch.Generator().manual_seed(0)
+    G = torch.nn.functional.normalize(torch.randn((Ng, 256), generator=gen), dim=-1)
+    if Ng > 600:
+        G[600] = G[3]                                   # a tie across the two shards
+    Q = torch.nn.functional.normalize(torch.randn((6, 256), generator=gen), dim=-1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), G, Q, k, out), nprocs=2, join=True)
+    rs, ri = oret.similarity_topk(Q, G, k)
+    kk = min(k, Ng)
+    assert torch.equal(out["i"][:, :kk], ri) and torch.allclose(out["s"][:, :kk], rs)
+    if k > Ng:
+        assert (out["i"][:, Ng:] == -1).all()

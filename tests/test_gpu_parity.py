@@ -484,3 +484,18 @@ def test_similarity_topk(Bq, Ng, k, gdt):
     assert same.all(), f"top-k index mismatch at {(~same).nonzero()[:5]}"
     if k > Ng:
         assert (i[:, Ng:] == -1).all() and torch.isinf(s[:, Ng:]).all()
+
+
+@pytest.mark.parametrize("Bq,Ng,k", [(8, 5000, 10), (33, 1237, 32)])
+def test_similarity_topk_fp32_bitwise_vs_fma_chain_oracle(Bq, Ng, k):
+    """fp32 gallery: the f32 MFMA is a k-ordered fmaf chain, restated in oracle/c/sim_chain.c -> scores must be
+    BIT-IDENTICAL and hence the top-k indices identical, ties included (north-star: bit-exact top-k indices)."""
+    ops, _ = _ops()
+    rng = np.random.default_rng(Bq * Ng)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Bq, 256), dtype=np.float32)), dim=-1)
+    G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Ng, 256), dtype=np.float32)), dim=-1)
+    G[11] = G[7]; G[Ng - 1] = G[2]
+    s, i = ops.similarity_topk(Q.to(DEV), G.to(DEV), k)
+    rs, ri = oret.similarity_topk(Q, G, k, exact_chain=True)
+    assert torch.equal(i.cpu(), ri), "top-k indices differ from the bit-exact oracle"
+    assert torch.equal(s.cpu().view(torch.int32), rs.view(torch.int32)), "scores are not bit-identical"
