@@ -159,6 +159,89 @@ __global__ void __launch_bounds__(NT) attn_rowlane(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// attn_fewq: a handful of queries (<= 8) against thousands of keys — the decoder's token -> image cross attention
+// (6 tokens x 4096 image keys, 8 heads x 16; lib/sam_model/transformer.py:163-166,99-100). One query per lane would
+// leave 58 of 64 lanes idle and walk 4096 keys serially (measured 2.6 ms per launch); here the KEYS are spread over
+// the 256 lanes of a block (one block per (batch, head)), every lane keeps a private online-softmax state for all
+// queries, and the partial states are merged once at the end (wave shuffles, then LDS across the 4 waves).
+template <typename T, typename TO, int HD, int TQ>
+__global__ void __launch_bounds__(256) attn_fewq(const AttnArgs a) {
+  __shared__ float qs[TQ][HD];
+  __shared__ float red[4][TQ][HD + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const T* qb = (const T*)a.q + b * a.q_sb + h * HD;
+  const T* kb = (const T*)a.k + b * a.k_sb + h * HD;
+  const T* vb = (const T*)a.v + b * a.v_sb + h * HD;
+  for (int i = tid; i < TQ * HD; i += 256) {
+    const int qi = i / HD, d = i - qi * HD;
+    qs[qi][d] = qi < a.Tq ? ld<T>(qb + (long)qi * a.q_st + d) * a.scale : 0.f;
+  }
+  __syncthreads();
+  float m[TQ], l[TQ], o[TQ][HD];
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    m[qi] = -INFINITY; l[qi] = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[qi][d] = 0.f;
+  }
+  for (int j = tid; j < a.Tk; j += 256) {
+    float kv[HD], vv[HD];
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+      const f32x4 k4 = ld4<T>(kb + (long)j * a.k_st + 4 * i), v4 = ld4<T>(vb + (long)j * a.v_st + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kv[4 * i + e] = k4[e]; vv[4 * i + e] = v4[e]; }
+    }
+#pragma unroll
+    for (int qi = 0; qi < TQ; ++qi) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) sc = fmaf(qs[qi][d], kv[d], sc);
+      const float mn = fmaxf(m[qi], sc);
+      const float alpha = __expf(m[qi] - mn), p = __expf(sc - mn);
+      l[qi] = l[qi] * alpha + p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[qi][d] = fmaf(p, vv[d], o[qi][d] * alpha);
+      m[qi] = mn;
+    }
+  }
+  // merge the 64 lane states of a wave, then the 4 waves
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    const float mw = wave_max(m[qi]);
+    const float f = m[qi] == -INFINITY ? 0.f : __expf(m[qi] - mw);
+    const float lw = wave_sum(l[qi] * f);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[qi][d] = wave_sum(o[qi][d] * f);
+    if (lane == 0) {
+      red[wave][qi][HD] = mw; red[wave][qi][HD + 1] = lw;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) red[wave][qi][d] = o[qi][d];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.Tq * HD; i += 256) {
+    const int qi = i / HD, d = i - qi * HD;
+    float mm = -INFINITY;
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][qi][HD]);
+    float num = 0.f, den = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      const float f = red[w][qi][HD] == -INFINITY ? 0.f : __expf(red[w][qi][HD] - mm);
+      num += red[w][qi][d] * f; den += red[w][qi][HD + 1] * f;
+    }
+    st<TO>((TO*)a.o + b * a.o_sb + (long)qi * a.o_st + h * HD + d, num / den);
+  }
+}
+
+template <typename T, typename TO>
+int launch_fewq(const AttnArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL((attn_fewq<T, TO, 16, 8>), dim3(a.H, B), dim3(256), 0, s, a);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, typename TO, int HD, int MODE>
 int launch_rowlane(const AttnArgs& a, int nb, hipStream_t s) {
   const size_t lds = MODE == 0 ? 0 : (size_t)a.S * NT * sizeof(float);
@@ -199,6 +282,12 @@ extern "C" int cor_attention(const void* q, long q_sb, long q_st, const void* k,
   a.q = q; a.k = k; a.v = v; a.o = out;
   a.q_sb = q_sb; a.q_st = q_st; a.k_sb = k_sb; a.k_st = k_st; a.v_sb = v_sb; a.v_st = v_st; a.o_sb = o_sb; a.o_st = o_st;
   a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.S = 0;
+  if (hd == 16 && Tq <= 8 && Tk >= 512) {
+    if (dtype == COR_F32 && out_dtype == COR_F32) return launch_fewq<float, float>(a, B, s);
+    if (dtype == COR_BF16 && out_dtype == COR_BF16) return launch_fewq<bf16_t, bf16_t>(a, B, s);
+    if (dtype == COR_BF16 && out_dtype == COR_F32) return launch_fewq<bf16_t, float>(a, B, s);
+    if (dtype == COR_F32 && out_dtype == COR_BF16) return launch_fewq<float, bf16_t>(a, B, s);
+  }
   switch (hd) {
     case 16: return dispatch_types<16, 0>(a, B, dtype, out_dtype, s);
     case 32: return dispatch_types<32, 0>(a, B, dtype, out_dtype, s);

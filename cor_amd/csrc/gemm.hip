@@ -31,6 +31,7 @@ struct GemmArgs {
   int tm, tn;
   const float* bias; const float* col_scale; const float* residual;
   long ldr; int res_row_mod; int act;
+  int dbg;             // timing-only ablation knobs (tools/gemm_ksweep.py): 1 no C stores, 2 no epilogue, 4 no MFMA
   int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
 };
 
@@ -57,6 +58,105 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Vectorised epilogue shared by the tile kernels. The MFMA C layout gives a lane one column (2-4 B stores: ~1 TB/s
+// measured), so each wave transposes 32-row slabs of its tile through LDS (`stg`, wave-private, [32][WTN] floats inside
+// the idle K-loop buffers) and every lane then owns VW CONSECUTIVE columns of one row: 16-B loads and one 16-B store.
+// All bias / scale / residual loads of a slab are issued BEFORE any of them is consumed, from clamped (always valid)
+// addresses: with per-element predicated loads hipcc serialised "load, s_waitcnt vmcnt(0), use" 8-16 times per tile,
+// which cost ~7 us per tile (ablation in tools/gemm_ksweep.py) - more than the K loop at K = 768.
+template <int ACT> __device__ __forceinline__ float act_ct(float v) {
+  if constexpr (ACT == COR_ACT_GELU_ERF) return gelu_erf_f(v);
+  else if constexpr (ACT == COR_ACT_RELU) return fmaxf(v, 0.0f);
+  else if constexpr (ACT == COR_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  else if constexpr (ACT == COR_ACT_GELU_TANH) return gelu_tanh_f(v);
+  else return v;
+}
+
+// ACT / HAS_RES are compile-time: a per-element runtime switch broke the slab into ~10 basic blocks per element.
+template <typename TO, int MI, int NJ, int WTN, int ACT, bool HAS_RES>
+__device__ __forceinline__ void epilogue_vec_ct(const f32x16 (&acc)[MI][NJ], float* stg, const GemmArgs& g, int mbase, int nbase,
+                                                int lane) {
+  constexpr int VW = sizeof(TO) == 2 ? 8 : 4;         // columns per lane: one 16-B store either way
+  constexpr int CV = WTN / VW;                        // lanes per staged row
+  constexpr int NJV = (32 * CV) / 64;                 // row groups per 32-row slab
+  constexpr int Q4 = VW / 4;
+  const int r = lane & 31, h = lane >> 5;
+  const int cv = lane % CV, row0 = lane / CV;         // lane's column group is the same for every row group
+  const int n = nbase + cv * VW;
+  const int nc = min(n, g.N - VW < 0 ? 0 : g.N - VW); // clamped column for loads (N % 4 == 0; N >= 4)
+  TO* C = (TO*)g.C;
+  f32x4 bv[Q4], sv[Q4];
+#pragma unroll
+  for (int q4 = 0; q4 < Q4; ++q4) {
+    const int nn = min(n + 4 * q4, g.N - 4);
+    bv[q4] = g.bias ? *(const f32x4*)(g.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sv[q4] = g.col_scale ? *(const f32x4*)(g.col_scale + nn) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  (void)nc;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    f32x4 res[NJV][Q4];
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int j = 0; j < NJV; ++j) {
+        const int m = min(mbase + mi * 32 + j * (64 / CV) + row0, g.M - 1);
+        const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
+#pragma unroll
+        for (int q4 = 0; q4 < Q4; ++q4) res[j][q4] = *(const f32x4*)(g.residual + (long)rr * g.ldr + min(n + 4 * q4, g.N - 4));
+      }
+    }
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * h) * WTN + nj * 32 + r] = acc[mi][nj][e];
+#pragma unroll
+    for (int j = 0; j < NJV; ++j) {
+      const int row = j * (64 / CV) + row0;
+      const int m = mbase + mi * 32 + row;
+      f32x4 v[Q4];
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; ++q4) {
+        v[q4] = *(const f32x4*)(stg + row * WTN + cv * VW + 4 * q4) + bv[q4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT>(v[q4][q]);
+        v[q4] *= sv[q4];
+        if constexpr (HAS_RES) v[q4] += res[j][q4];
+      }
+      if (m < g.M && n < g.N && !(g.dbg & 1)) {
+        TO* cp = C + (long)m * g.ldc + n;
+        if constexpr (VW == 8) {
+          if (n + 8 <= g.N) {
+            uint4 u;
+            u.x = (uint32_t)f2bf(v[0][0]) | ((uint32_t)f2bf(v[0][1]) << 16); u.y = (uint32_t)f2bf(v[0][2]) | ((uint32_t)f2bf(v[0][3]) << 16);
+            u.z = (uint32_t)f2bf(v[1][0]) | ((uint32_t)f2bf(v[1][1]) << 16); u.w = (uint32_t)f2bf(v[1][2]) | ((uint32_t)f2bf(v[1][3]) << 16);
+            *(uint4*)cp = u;
+          } else {
+            st4<TO>(cp, v[0]);
+          }
+        } else {
+          st4<TO>(cp, v[0]);
+        }
+      }
+    }
+  }
+}
+
+template <typename TO, int MI, int NJ, int WTN>
+__device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MI][NJ], float* stg, const GemmArgs& g, int mbase, int nbase,
+                                             int lane) {
+#define COR_EPI(A_)                                                                                            \
+  if (g.residual) epilogue_vec_ct<TO, MI, NJ, WTN, A_, true>(acc, stg, g, mbase, nbase, lane);                \
+  else epilogue_vec_ct<TO, MI, NJ, WTN, A_, false>(acc, stg, g, mbase, nbase, lane);
+  switch (g.act) {                                    // wave-uniform
+    case COR_ACT_GELU_ERF: COR_EPI(COR_ACT_GELU_ERF) break;
+    case COR_ACT_RELU: COR_EPI(COR_ACT_RELU) break;
+    case COR_ACT_SIGMOID: COR_EPI(COR_ACT_SIGMOID) break;
+    case COR_ACT_GELU_TANH: COR_EPI(COR_ACT_GELU_TANH) break;
+    default: COR_EPI(COR_ACT_NONE) break;
+  }
+#undef COR_EPI
 }
 
 // Tile-parametrised kernel. BM x BN block tile, WM x WN waves (each (BM/WM) x (BN/WN) = MI x NJ MFMA 32x32 tiles).
@@ -183,51 +283,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {
   // 16-B bias/residual loads, 16-B (fp32) or 8-B (bf16) stores, whole 128/256-B row segments per 16 lanes.
   TO* C = (TO*)g.C;
   if (g.vec_epi) {
-    float* stg = (float*)smem + wave * (32 * WTN);
-    constexpr int VW = sizeof(TO) == 2 ? 8 : 4;       // columns per lane: one 16-B store either way
-    constexpr int CV = WTN / VW;                      // lanes per staged row
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * h) * WTN + nj * 32 + r] = acc[mi][nj][e];
-#pragma unroll
-      for (int j = 0; j < (32 * CV) / 64; ++j) {
-        const int idx = j * 64 + lane, row = idx / CV, cv = idx - row * CV;
-        const int m = m0 + wm * WTM + mi * 32 + row, n = n0 + wn * WTN + cv * VW;
-        f32x4 v[VW / 4];
-#pragma unroll
-        for (int q4 = 0; q4 < VW / 4; ++q4) v[q4] = *(const f32x4*)(stg + row * WTN + cv * VW + 4 * q4);
-        if (m < g.M && n < g.N) {
-          const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
-#pragma unroll
-          for (int q4 = 0; q4 < VW / 4; ++q4) {
-            const int nn = n + 4 * q4;
-            if (nn < g.N) {                           // N % 4 == 0: a group of 4 is all-in or all-out
-              if (g.bias) v[q4] += *(const f32x4*)(g.bias + nn);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q4][q] = apply_act(v[q4][q], g.act);
-              if (g.col_scale) v[q4] *= *(const f32x4*)(g.col_scale + nn);
-              if (g.residual) v[q4] += *(const f32x4*)(g.residual + (long)rr * g.ldr + nn);
-            }
-          }
-          TO* cp = C + (long)m * g.ldc + n;
-          if constexpr (VW == 8) {
-            if (n + 8 <= g.N) {
-              uint4 u;
-              u.x = (uint32_t)f2bf(v[0][0]) | ((uint32_t)f2bf(v[0][1]) << 16); u.y = (uint32_t)f2bf(v[0][2]) | ((uint32_t)f2bf(v[0][3]) << 16);
-              u.z = (uint32_t)f2bf(v[1][0]) | ((uint32_t)f2bf(v[1][1]) << 16); u.w = (uint32_t)f2bf(v[1][2]) | ((uint32_t)f2bf(v[1][3]) << 16);
-              *(uint4*)cp = u;
-            } else {
-              st4<TO>(cp, v[0]);
-            }
-          } else {
-            st4<TO>(cp, v[0]);
-          }
-        }
-      }
-    }
+    epilogue_vec<TO, MI, NJ, WTN>(acc, (float*)smem + wave * (32 * WTN), g, m0 + wm * WTM, n0 + wn * WTN, lane);
     return;
   }
 #pragma unroll
@@ -250,6 +306,141 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {
         st<TO>(C + (long)m * g.ldc + n, v);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent variant (128x128 tile, 4 waves, LDS-DMA): 2 blocks per CU walk the tile space; the K-step sequence of a
+// block runs straight through tile boundaries — the DMA of the NEXT tile's first K-step is issued before the epilogue of
+// the current tile (into the LDS buffer the epilogue does not use) and the epilogue's global stores drain under the next
+// tile's MFMAs. This removes the exposed per-tile prologue/epilogue (measured ~11 us per tile at 2 blocks/CU, i.e. as
+// much as 40 K-steps) that bounds the one-tile-per-block kernel at K = 768.
+template <typename TA, typename TO>
+__global__ void __launch_bounds__(256, 2) gemm_persist(const GemmArgs g) {
+  constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, MI = 2, NJ = 2, NT = 256;
+  constexpr int A_BYTES = BM * ROWB, BUF = 2 * A_BYTES, ACH = 4, BCH = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned wslot = __builtin_amdgcn_readfirstlane(tid & ~63) * 16;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+
+  // ---- this block's share of the tile space: blocks with equal (bid % 8) share an XCD (speed only) and take one
+  //      contiguous chunk of tiles (N-tiles of one A row-panel are neighbours => L2 reuse of A), walked in rounds.
+  const int total = g.tm * g.tn, nb8 = gridDim.x >> 3;            // gridDim.x % 8 == 0 (launcher)
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int q8 = total >> 3, r8 = total & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunkn = q8 + (xcd < r8 ? 1 : 0);
+
+  const int r = lane & 31, h = lane >> 5, sw = (lane >> 1) & 7;
+  const int a_rd = (wm * WTM + r) * ROWB, b_rd = A_BYTES + (wn * WTN + r) * ROWB;
+  int ch_rd[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ch_rd[s] = ((2 * s + h) ^ sw) << 4;
+  const int nkt = g.Kb / ROWB;                                    // K bytes % 128 == 0 (launcher)
+
+  const char* a_src[ACH]; const char* b_src[BCH];
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    m0 = (t / g.tn) * BM; n0 = (t % g.tn) * BN;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int c = tid + NT * i, row = c >> 3, ch = (c & 7) ^ ((row >> 1) & 7);
+      a_src[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda_b + ch * 16;
+      b_src[i] = g.W + (long)min(n0 + row, g.N - 1) * g.ldw_b + ch * 16;
+    }
+  };
+  auto issue = [&](int kt, int buf) {
+    const unsigned base = lds0 + buf * BUF + wslot;
+    const int kb = kt * ROWB;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) glds16(a_src[i] + kb, base + NT * 16 * i);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) glds16(b_src[i] + kb, base + A_BYTES + NT * 16 * i);
+  };
+
+  int li = lb;                                                    // local tile index inside the chunk
+  if (li >= chunkn) return;                                       // whole block idle (uniform)
+  // The two blocks resident on a CU run identical work and would sit in their epilogues (no MFMA) at the same time.
+  // Delay the second-dispatched half by about half a tile period so one block's epilogue overlaps the other's K loop
+  // (which blocks share a CU is the dispatcher's choice: this is a speed heuristic only).
+  if ((g.dbg & 8) && lb >= (nb8 >> 1)) {
+    const int naps = (nkt * 550 + 2500) / (64 * 100);
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+  set_tile(chunk0 + li);
+  int gs = 0;                                                     // global K-step counter: buffer = gs & 1
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TO* C = (TO*)g.C;
+  while (true) {
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const bool more = kt + 1 < nkt;
+      if (more) issue(kt + 1, (gs + 1) & 1);
+      const char* buf = smem + (gs & 1) * BUF;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        uint4 af[MI], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const uint4*)(buf + a_rd + i * 32 * ROWB + ch_rd[s]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = *(const uint4*)(buf + b_rd + j * 32 * ROWB + ch_rd[s]);
+        if (!(g.dbg & 4)) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) Mfma<TA>::run(af[i], bf[j], acc[i][j]);
+        } else {
+          asm volatile("" :: "v"(af[0].x), "v"(bf[0].x), "v"(af[1].y), "v"(bf[1].y));
+        }
+      }
+      if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      ++gs;
+    }
+    // ---- tile boundary: buffer (gs-1)&1 was just consumed by every wave (barrier above) -> epilogue staging;
+    //      buffer gs&1 is free -> DMA target of the next tile's first K-step, issued BEFORE the epilogue.
+    const int cm0 = m0, cn0 = n0;
+    li += nb8;
+    const bool next = li < chunkn;
+    if (next) { set_tile(chunk0 + li); issue(0, gs & 1); }
+    float* stg = (float*)(smem + ((gs - 1) & 1) * BUF) + wave * (32 * WTN);
+    if (g.dbg & 2) {
+      asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[1][0][9]), "v"(acc[1][1][15]));
+    } else if (g.vec_epi) {
+      epilogue_vec<TO, MI, NJ, WTN>(acc, stg, g, cm0 + wm * WTM, cn0 + wn * WTN, lane);
+    } else {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        const int n = cn0 + wn * WTN + nj * 32 + r;
+        if (n < g.N) {
+          const float bv = g.bias ? g.bias[n] : 0.0f, sc = g.col_scale ? g.col_scale[n] : 1.0f;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int m = cm0 + wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              if (m < g.M) {
+                float v = apply_act(acc[mi][nj][e] + bv, g.act) * sc;
+                if (g.residual) v += g.residual[(long)(g.res_row_mod > 0 ? m % g.res_row_mod : m) * g.ldr + n];
+                st<TO>(C + (long)m * g.ldc + n, v);
+              }
+            }
+        }
+      }
+    }
+    if (!next) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // next tile's first K-step has landed (this wave's part)
+    __syncthreads();                                               // ... for every wave; staging buffer may now be re-filled
   }
 }
 
@@ -293,7 +484,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, cons
   }
 }
 
-int g_gemm_cfg = 0;   // 0 = auto; 1..6 force a tile configuration (tools/gemm_bench.py)
+int g_gemm_cfg = 0, g_gemm_dbg = 0;   // 0 = auto; 1..6 force a tile configuration (tools/gemm_bench.py)
 
 template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS>
 int launch_tile(GemmArgs g, hipStream_t s) {
@@ -327,13 +518,36 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
   g.M = M; g.N = N; g.Kb = (int)(K * esz);
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
+  g.dbg = g_gemm_dbg;
   const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  g.vec_epi = (N % 4 == 0) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
+  g.vec_epi = (N % 4 == 0) && (N >= 8) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
               (!residual || (al16(residual) && ldr % 4 == 0));
   const bool k128 = g.Kb % ROWB == 0;                 // direct-to-LDS staging cannot zero-fill a K tail
   int cfg = g_gemm_cfg;
   if (cfg == 0) cfg = (k128 && M >= 512 && N >= 64) ? COR_GEMM_DEFAULT_BIG : 1;
   if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
+  if (cfg == 7) {
+    if (!k128) cfg = 1;
+    else {
+      g.tm = cdiv(g.M, 128); g.tn = cdiv(g.N, 128);
+      static int n_cu = 0;
+      static bool attr_set = false;
+      if (!attr_set) {
+        int dev = 0; hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        (void)hipFuncSetAttribute((const void*)gemm_persist<TA, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * ROWB);
+        attr_set = true;
+      }
+      int blocks = 2 * n_cu;                                        // 2 resident blocks per CU (64 KiB LDS each)
+      blocks -= blocks & 7;
+      const int total = g.tm * g.tn;
+      if (total < blocks) blocks = ((total + 7) / 8) * 8;           // idle blocks return at once
+      hipLaunchKernelGGL((gemm_persist<TA, TO>), dim3(blocks), dim3(256), 4 * 128 * ROWB, s, g);
+      COR_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   switch (cfg) {
     case 2: return launch_tile<TA, TO, 128, 128, 2, 2, true>(g, s);
     case 3: return launch_tile<TA, TO, 256, 128, 4, 2, true>(g, s);
@@ -347,7 +561,8 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
 }  // namespace
 
 extern "C" int cor_gemm_set_config(int cfg) {
-  if (cfg < 0 || cfg > 6) return COR_EINVAL;
+  if (cfg >= 100) { g_gemm_dbg = cfg - 100; return 0; }            // timing-only ablation knobs (persistent kernel)
+  if (cfg < 0 || cfg > 7) return COR_EINVAL;
   g_gemm_cfg = cfg;
   return 0;
 }

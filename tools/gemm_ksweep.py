@@ -6,17 +6,20 @@ sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops, _native
 lib = _native.load(); dev = "cuda:0"; T = torch.bfloat16
-cfgs = [int(c) for c in sys.argv[1:]] or [2, 3]
+cfgs = [int(c) for c in sys.argv[1:]] or [2, 3]   # 7xx = persistent kernel with ablation knob xx (1 no stores, 2 no epilogue, 4 no MFMA)
 M, N = 131072, 768
-for mode in ("bf16_out", "f32_out", "f32_out_res", "bf16_out_gelu"):
-    for K in (64, 256, 768, 1536, 3072):
+for mode in ("bf16_out", "f32_out_res"):
+    for K in (64, 768, 3072):
         A = torch.randn((M, K), device=dev).to(T); W = (torch.randn((N, K), device=dev) / K ** 0.5).to(T)
         bias = torch.randn((N,), device=dev); R = torch.randn((M, N), device=dev) if mode == "f32_out_res" else None
         od = T if mode.startswith("bf16") else torch.float32
         act = 1 if mode.endswith("gelu") else 0
         row = dict(mode=mode, K=K)
         for c in cfgs:
-            lib.cor_gemm_set_config(c)
+            if c >= 700:
+                lib.cor_gemm_set_config(7); lib.cor_gemm_set_config(100 + c - 700)
+            else:
+                lib.cor_gemm_set_config(c); lib.cor_gemm_set_config(100)
             ts = []
             for i in range(6):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,4 +27,4 @@ for mode in ("bf16_out", "f32_out", "f32_out_res", "bf16_out_gelu"):
                 ts.append(e0.elapsed_time(e1))
             row[f"cfg{c}_us"] = round(min(ts[1:]) * 1e3, 1)
         print(json.dumps(row), flush=True)
-lib.cor_gemm_set_config(0)
+lib.cor_gemm_set_config(0); lib.cor_gemm_set_config(100)
