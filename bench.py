@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
     return ap.parse_args()
 
 
@@ -67,12 +68,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = 0                                   # rehearsal: all ranks share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
     from cor_amd import ops, retrieval, utils
     from cor_amd.lib.build_model import build_model_with_query_support_feat
@@ -110,7 +116,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device="cpu" if args.backend == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -15,6 +15,8 @@
 //   windowed (S = 14): both parts are looked up per score in two small per-wave LDS tables.
 // Window partition, zero padding (a padded token's q/k/v is the qkv bias row) and un-partition are addressing only.
 // Scores are kept in the log2 domain (scale*log2e folded in) so the exponential is a bare v_exp_f32.
+#include <type_traits>
+
 #include "common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -28,6 +30,7 @@ struct FlashArgs {
   float scale_log2;                                     // softmax scale * log2(e)
   const bf16_t* pad_row; const float* rel_h; const float* rel_w;
   int grid, S, nW, d3;                                  // SAM: image grid, rel-pos size, windows per side, 3*H*64
+  int nqt;                                              // query tiles (128 queries) per (batch, head)
 };
 
 constexpr int KT = 64;                       // keys per tile
@@ -38,7 +41,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-__device__ __forceinline__ uint32_t pk2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32 per pair (two scalar casts + shift/or cost 4 instructions)
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ uint4 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
   uint4 u;
   u.x = pk2(f0, f1); u.y = pk2(f2, f3); u.z = pk2(f4, f5); u.w = pk2(f6, f7);
@@ -57,7 +66,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, bz = blockIdx.z;
+  // XCD-aware placement: the nqt query tiles of one (batch, head) re-read the same K/V (1 MiB at 4096 keys); hand each
+  // XCD (blocks with equal id % 8) a contiguous run of work items so those re-reads hit ITS L2 instead of HBM/MALL.
+  const int wi_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
+  const int head = hb_ % a.H, bz = hb_ / a.H;
   const int S = a.S;
 
   // ---- problem geometry
@@ -85,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   };
 
   // ---- this lane's query
-  int tq = blockIdx.x * 128 + wave * 32 + r;
+  int tq = qt_ * 128 + wave * 32 + r;
   bool qvalid = tq < a.Tq;
   tq = min(tq, a.Tq - 1);
   const int qh = MODE == 0 ? 0 : tq / S, qw = MODE == 0 ? 0 : tq - (tq / S) * S;
@@ -205,10 +218,9 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   float m = -INFINITY, l = 0.f;
 
   const int nt = (a.Tk + KT - 1) / KT;
-  FA_GLOAD(0)
-  FA_LSTORE(0)
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
+  // one K/V tile; TAIL = the last, partially filled tile (the only one that needs per-key masking)
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const bool more = t + 1 < nt;
     if (more) FA_GLOAD(t + 1)
     const char* Ks = smem + (t & 1) * 2 * TILE_B; const char* Vs = Ks + TILE_B;
@@ -225,30 +237,32 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
       }
     }
-    // logits in the log2 domain, bias, mask, running max
+    // logits in the log2 domain. MODE 1: the per-tile row term rh is the same for all 64 keys of the tile, so it is
+    // folded into the running-max bookkeeping instead of being added to 32 registers.
     const float rh = MODE == 1 ? aux[t * 32 + r] : 0.f;
-    const bool tail = (t == nt - 1) && (a.Tk & (KT - 1));
     float mloc = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float x = s[kb][e] * a.scale_log2;
-        const int kidx = t * KT + kb * 32 + acc_row(e, h);
-        if (MODE == 1) x += wreg[kb][e] + rh;
-        if (MODE == 2) {
-          const int kc = min(kidx, a.Tk - 1);
-          const int kh = (kc * 4682) >> 16;            // kc / 14 for kc < 256 (S == 14 checked by the launcher)
-          const int kw = kc - kh * 14;
-          x += aux[(qh - kh + 13) * 32 + r] + aux[1024 + (qw - kw + 13) * 32 + r];
+        float x = MODE == 1 ? fmaf(s[kb][e], a.scale_log2, wreg[kb][e]) : s[kb][e] * a.scale_log2;
+        if (MODE == 2 || TAIL) {
+          const int kidx = t * KT + kb * 32 + acc_row(e, h);
+          if (MODE == 2) {
+            const int kc = min(kidx, a.Tk - 1);
+            const int kh = (kc * 4682) >> 16;          // kc / 14 for kc < 256 (S == 14 checked by the launcher)
+            const int kw = kc - kh * 14;
+            x += aux[(qh - kh + 13) * 32 + r] + aux[1024 + (qw - kw + 13) * 32 + r];
+          }
+          if (TAIL && kidx >= a.Tk) x = -INFINITY;
         }
-        if (tail && kidx >= a.Tk) x = -INFINITY;
         s[kb][e] = x;
         mloc = fmaxf(mloc, x);
       }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) + rh;  // true tile max (x + rh)
     const float mnew = fmaxf(m, mloc);
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    const float msub = mnew - rh;                       // p = 2^(x + rh - mnew)
     m = mnew;
     l *= alpha;
 #pragma unroll
@@ -260,7 +274,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 p;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(s[kb][e] - mnew); l += p[e]; }
+      for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub); l += p[e]; }
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
@@ -282,7 +296,13 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       }
     if (more) FA_LSTORE((t + 1) & 1)
     __syncthreads();
-  }
+  };
+  FA_GLOAD(0)
+  FA_LSTORE(0)
+  __syncthreads();
+  const int nfull = (a.Tk & (KT - 1)) ? nt - 1 : nt;
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < nt) tile(nt - 1, std::true_type{});
 
   l += __shfl_xor(l, 32, 64);
   if (!qvalid) return;
@@ -305,7 +325,9 @@ int launch(const FlashArgs& a, int nb, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)flash_fwd<MODE, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_fwd<MODE, TO>), dim3(cdiv(a.Tq, 128), a.H, nb), dim3(256), lds, s, a);
+  FlashArgs b = a;
+  b.nqt = cdiv(a.Tq, 128);
+  hipLaunchKernelGGL((flash_fwd<MODE, TO>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
 }

@@ -31,6 +31,7 @@ struct GemmArgs {
   int tm, tn;
   const float* bias; const float* col_scale; const float* residual;
   long ldr; int res_row_mod; int act;
+  int group_m;         // tile order: M-panels per band (L2 blocking)
   int dbg;             // timing-only ablation knobs (tools/gemm_ksweep.py): 1 no C stores, 2 no epilogue, 4 no MFMA
   int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
 };
@@ -174,7 +175,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (swz / g.tn) * BM, n0 = (swz % g.tn) * BN;
+  // Grouped tile order inside an XCD's contiguous chunk: bands of GM row-panels, column-major inside a band, so the ~64
+  // blocks resident on an XCD cover GM A-panels x (64/GM) W-panels whose ~3 MB fit the 4 MiB L2 (row-major order made
+  // every block of a wide-N GEMM miss on W: 14x over-fetch measured with FETCH_SIZE on the N=3072 MLP GEMM).
+  const int GM = g.group_m;
+  const int band = swz / (GM * g.tn), rem = swz - band * (GM * g.tn);
+  const int gm_eff = min(GM, g.tm - band * GM);
+  const int m0 = (band * GM + rem % gm_eff) * BM, n0 = (rem / gm_eff) * BN;
 
   // ---- staging map: thread owns LDS chunk slots c = tid + NT*i (linear image: slot c lives at byte 16*c);
   //      slot (row, sl) holds source chunk sl ^ ((row>>1)&7) of that row
@@ -519,6 +526,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.M = M; g.N = N; g.Kb = (int)(K * esz);
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
   g.dbg = g_gemm_dbg;
+  g.group_m = (g_gemm_dbg >> 4) ? (g_gemm_dbg >> 4) : 8;
   const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   g.vec_epi = (N % 4 == 0) && (N >= 8) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
               (!residual || (al16(residual) && ldr % 4 == 0));

@@ -74,10 +74,16 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
         return s.cpu(), i.cpu()
     world = dist.get_world_size(group)
     q = local_queries.reshape(-1, local_queries.shape[-1]).to(torch.float32).contiguous()
+    dev = q.device
+    host_coll = dist.get_backend(group) == "gloo"               # CPU rehearsal backend: collectives on host copies
+    if host_coll:
+        q = q.cpu()
     gathered = [torch.empty_like(q) for _ in range(world)]
     dist.all_gather(gathered, q, group=group)                    # the one data-path collective (RCCL over xGMI)
-    allq = torch.cat(gathered, dim=0)
+    allq = torch.cat(gathered, dim=0).to(dev)
     s, i = shard.search(allq, k)                                 # local shard vs ALL queries
+    if host_coll:
+        s, i = s.cpu(), i.cpu()
     s_parts = [torch.empty_like(s) for _ in range(world)]
     i_parts = [torch.empty_like(i) for _ in range(world)]
     dist.all_gather(s_parts, s, group=group)                     # 12 B * B_total * k per rank

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark of the SAM attention kernels (global / windowed) at SAM-B shape. python tools/attn_bench.py [B]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from cor_amd import ops
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+H, g, dev, T = 12, 64, "cuda:0", torch.bfloat16
+d = H * 64
+qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T)
+pad = torch.randn((3 * d,), device=dev).to(T)
+for window, S in ((0, 64), (14, 14)):
+    rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5
+    rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
+    ts = []
+    for i in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.sam_attention(qkv, pad, rh, rw, B, H, g, window); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    fl = (4.0 * (g * g) ** 2 * 64 if window == 0 else 25 * 4.0 * 196 ** 2 * 64) * H * B
+    print(json.dumps(dict(window=window, B=B, ms=min(ts[1:]), tflops=fl / (min(ts[1:]) * 1e-3) / 1e12)), flush=True)
