@@ -41,6 +41,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
+// value of lane (l ^ 32): v_permlane32_swap (VALU) instead of a ds_bpermute round trip through the LDS pipe
+__device__ __forceinline__ float other_half(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = low-half values, r[1] = high-half values
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // one v_cvt_pk_bf16_f32 per pair (two scalar casts + shift/or cost 4 instructions)
@@ -179,9 +186,20 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) aux[tbl * 1024 + acc_row(e, h) * 32 + r] = acc[e] * LOG2E;
     }
+    // column part of the bias for this lane's 32 score registers: constant over tiles -> registers
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int loc = min(kb * 32 + acc_row(e, h), 55);
+        const int kw = loc - 14 * ((loc * 4682) >> 16);
+        wreg[kb][e] = aux[1024 + (qw - kw + 13) * 32 + r];
+      }
   }
 
-  // ---- staging map
+  // ---- staging map. Windowed mode: a tile is 4 whole key rows of the 14x14 window (56 keys; LDS rows 56..63 are
+  // loaded but masked), so a score's (key row, key column) inside the tile is a compile-time property of its register.
+  constexpr int TSTRIDE = MODE == 2 ? 56 : KT;
   const int srow = tid >> 3, sch = tid & 7;                 // rows srow and srow+32
   const int k_st0 = srow * 128 + ((sch ^ ((srow >> 1) & 7)) << 4);
   const int k_st1 = (srow + 32) * 128 + ((sch ^ (((srow + 32) >> 1) & 7)) << 4);
@@ -190,9 +208,9 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #define FA_GLOAD(T_)                                                                   \
   {                                                                                    \
     const bf16_t *kp_, *vp_;                                                           \
-    kv_src(min((T_) * KT + srow, a.Tk - 1), kp_, vp_);                                 \
+    kv_src(min((T_) * TSTRIDE + srow, a.Tk - 1), kp_, vp_);                            \
     rk0 = *(const uint4*)(kp_ + sch * 8); rv0 = *(const uint4*)(vp_ + sch * 8);        \
-    kv_src(min((T_) * KT + srow + 32, a.Tk - 1), kp_, vp_);                            \
+    kv_src(min((T_) * TSTRIDE + srow + 32, a.Tk - 1), kp_, vp_);                       \
     rk1 = *(const uint4*)(kp_ + sch * 8); rv1 = *(const uint4*)(vp_ + sch * 8);        \
   }
 #define FA_LSTORE(BUF_)                                                                \
@@ -217,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
   float m = -INFINITY, l = 0.f;
 
-  const int nt = (a.Tk + KT - 1) / KT;
+  const int nt = (a.Tk + TSTRIDE - 1) / TSTRIDE;
   // one K/V tile; TAIL = the last, partially filled tile (the only one that needs per-key masking)
   auto tile = [&](int t, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
@@ -238,28 +256,49 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       }
     }
     // logits in the log2 domain. MODE 1: the per-tile row term rh is the same for all 64 keys of the tile, so it is
-    // folded into the running-max bookkeeping instead of being added to 32 registers.
+    // folded into the running-max bookkeeping instead of being added to 32 registers. MODE 2: the tile holds key rows
+    // 4t..4t+3; the row term is one of 4 per-tile LDS scalars, selected per register at compile time (per lane half).
     const float rh = MODE == 1 ? aux[t * 32 + r] : 0.f;
+    float thv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) thv[j] = aux[max(qh - (4 * t + j) + 13, 0) * 32 + r];
+    }
     float mloc = -INFINITY;
+    if (MODE != 2) {                                     // scale (+ column bias) two registers per v_pk_fma_f32
+      const f32x2_t sc2 = {a.scale_log2, a.scale_log2};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          f32x2_t v = {s[kb][e], s[kb][e + 1]};
+          const f32x2_t w = {MODE == 1 ? wreg[kb][e] : 0.f, MODE == 1 ? wreg[kb][e + 1] : 0.f};
+          v = v * sc2 + w;
+          s[kb][e] = v[0]; s[kb][e + 1] = v[1];
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float x = MODE == 1 ? fmaf(s[kb][e], a.scale_log2, wreg[kb][e]) : s[kb][e] * a.scale_log2;
-        if (MODE == 2 || TAIL) {
-          const int kidx = t * KT + kb * 32 + acc_row(e, h);
-          if (MODE == 2) {
-            const int kc = min(kidx, a.Tk - 1);
-            const int kh = (kc * 4682) >> 16;          // kc / 14 for kc < 256 (S == 14 checked by the launcher)
-            const int kw = kc - kh * 14;
-            x += aux[(qh - kh + 13) * 32 + r] + aux[1024 + (qw - kw + 13) * 32 + r];
+        float x;
+        if (MODE == 2) {
+          const int l0 = kb * 32 + (e & 3) + 8 * (e >> 2), l1 = l0 + 4;      // key inside the tile for h = 0 / 1
+          const int lim = TAIL ? 28 : 56;                                    // last tile: key rows 12, 13 only
+          if (l0 >= lim) x = -INFINITY;                                      // (then l1 >= lim too)
+          else {
+            const float th0 = thv[l0 / 14], th1 = thv[l1 < 56 ? l1 / 14 : 0];
+            x = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]) + (h ? th1 : th0);
+            if (l1 >= lim && h) x = -INFINITY;
           }
-          if (TAIL && kidx >= a.Tk) x = -INFINITY;
+        } else {
+          x = s[kb][e];                                  // already scaled + biased (packed, below)
+          if (TAIL && t * KT + kb * 32 + acc_row(e, h) >= a.Tk) x = -INFINITY;
         }
         s[kb][e] = x;
         mloc = fmaxf(mloc, x);
       }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) + rh;  // true tile max (x + rh)
+    mloc = fmaxf(mloc, other_half(mloc)) + rh;  // true tile max (x + rh)
     const float mnew = fmaxf(m, mloc);
     const float alpha = __builtin_amdgcn_exp2f(m - mnew);
     const float msub = mnew - rh;                       // p = 2^(x + rh - mnew)
@@ -273,8 +312,16 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 p;
+      const f32x2_t ms2 = {msub, msub};
+      f32x2_t lacc = {0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub); l += p[e]; }
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2_t d = f32x2_t{s[kb][e], s[kb][e + 1]} - ms2;
+        const f32x2_t pe = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+        p[e] = pe[0]; p[e + 1] = pe[1];
+        lacc += pe;
+      }
+      l += lacc[0] + lacc[1];
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
@@ -300,11 +347,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   FA_GLOAD(0)
   FA_LSTORE(0)
   __syncthreads();
-  const int nfull = (a.Tk & (KT - 1)) ? nt - 1 : nt;
+  const int nfull = (a.Tk % TSTRIDE) ? nt - 1 : nt;
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < nt) tile(nt - 1, std::true_type{});
 
-  l += __shfl_xor(l, 32, 64);
+  l += other_half(l);
   if (!qvalid) return;
   const float inv = 1.0f / l;
   TO* op = MODE == 0 ? (TO*)a.o + bz * a.o_sb + (long)tq * a.o_st + head * 64 : (TO*)a.o + orow * (long)(a.H * 64) + head * 64;
