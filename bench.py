@@ -121,9 +121,20 @@ def main():
         dt = float(tmax.item())
 
     # dominant kernel: the MFMA GEMM. HIP events were recorded around every launch on the launch stream.
-    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, dt_ in prof if dt_ == T)
-    gemm_flops = sum(f for _, _, f, dt_ in prof if dt_ == T)
+    gemm_ms = sum(p[0].elapsed_time(p[1]) for p in prof if p[3] == T)
+    gemm_flops = sum(p[2] for p in prof if p[3] == T)
+    gemm_bytes = sum(p[4] for p in prof if p[3] == T)
     n_launch = sum(1 for p in prof if p[3] == T)
+    # HBM traffic of that kernel cannot be read live: it comes from the committed rocprofv3 --pmc passes of THIS command
+    # (tools/pmc_traffic.py -> profiles/*pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction), per launch.
+    traffic = None
+    import glob
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if tf and args.dtype == "bf16" and world == 1 and B == 32:
+        try:
+            traffic = json.load(open(tf[-1]))["bytes_per_launch"]
+        except Exception:
+            traffic = None
     peak = 2500.0 if T == torch.bfloat16 else 157.3
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
 
@@ -136,7 +147,8 @@ def main():
                                    + (f" sharded {world} ways (RCCL all-gather of queries, host top-k merge)" if world > 1 else ""),
                        "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
             "roofline": {"bound": "mfma", "kernel": f"gemm_nt_mfma<{args.dtype}>", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "launches_per_step": n_launch // max(args.steps, 1),
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, offline pass)",
+                         "algorithmic_bytes_per_launch": gemm_bytes / max(n_launch, 1), "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
         }
         if world == 1 and not args.no_cpu_baseline:

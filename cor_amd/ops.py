@@ -14,7 +14,7 @@ from ._native import ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TAN
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
-# entries are (start_event, end_event, algorithmic_flops, ab_dtype). None = no instrumentation.
+# entries are (start_event, end_event, algorithmic_flops, ab_dtype, algorithmic_bytes). None = no instrumentation.
 GEMM_PROFILE = None
 
 
@@ -76,7 +76,8 @@ def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual
                               _p(bias), act, _p(col_scale), _p(residual), ldr, res_row_mod, _s()), "cor_gemm")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, a.dtype))
+        nbytes = (M * K + N * K) * a.element_size() + M * N * out.element_size() + (M * N * 4 if residual is not None else 0)
+        prof.append((e0, e1, 2.0 * M * N * K, a.dtype, float(nbytes)))
     return out
 
 
