@@ -95,4 +95,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// global -> LDS direct copy of 16 B per lane (LDS-DMA): LDS destination = lds_dst (wave-uniform, in M0) + lane*16.
+// M0 is compiler-reserved, so it is saved, set, used and restored inside ONE asm statement. The copy is invisible to
+// hipcc's s_waitcnt bookkeeping: the caller drains it (s_waitcnt vmcnt) before the barrier that publishes the data.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

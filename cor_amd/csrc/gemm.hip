@@ -53,14 +53,6 @@ template <> struct Mfma<bf16_t> {
 
 constexpr int ROWB = 128;                              // bytes of K per tile row per K-step
 
-// global -> LDS direct copy of 16 B per lane: LDS destination = lds_dst (wave-uniform, in M0) + lane*16.
-// M0 is compiler-reserved, so it is saved, set, used and restored inside ONE asm statement.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // Vectorised epilogue shared by the tile kernels. The MFMA C layout gives a lane one column (2-4 B stores: ~1 TB/s
 // measured), so each wave transposes 32-row slabs of its tile through LDS (`stg`, wave-private, [32][WTN] floats inside
 // the idle K-loop buffers) and every lane then owns VW CONSECUTIVE columns of one row: 16-B loads and one 16-B store.

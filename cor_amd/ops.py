@@ -341,7 +341,7 @@ def iou_select(iou, hyper, k_off, Ksel):
     return best, sel
 
 
-def similarity_topk(Q, G, k, g_offset=0):
+def similarity_topk(Q, G, k, g_offset=0, check_overflow=True):
     """Top-k gallery rows per query by dot product; (score desc, index asc). Q fp32 [Bq,C]; G [Ng,C] fp32/bf16/fp16."""
     _dev(Q, G)
     assert Q.dtype == torch.float32 and Q.is_contiguous() and G.is_contiguous() and Q.dim() == 2 and G.dim() == 2
@@ -357,4 +357,12 @@ def similarity_topk(Q, G, k, g_offset=0):
     idx = torch.empty((Bq, k), dtype=torch.int64, device=Q.device)
     nat.check(lib.cor_similarity_topk(Q.data_ptr(), G.data_ptr(), _dt(G), Bq, Ng, Cq, k, int(g_offset), scores.data_ptr(),
                                       idx.data_ptr(), ws.data_ptr(), _s()), "cor_similarity_topk")
+    if check_overflow and Ng >= 32768 and G.dtype != torch.float32 and bool((idx[:, 0] == -2).any()):
+        # candidate-list overflow of the threshold-and-append path (pathological score distribution): exact list kernels
+        lib.cor_topk_set_mode(1)
+        try:
+            nat.check(lib.cor_similarity_topk(Q.data_ptr(), G.data_ptr(), _dt(G), Bq, Ng, Cq, k, int(g_offset), scores.data_ptr(),
+                                              idx.data_ptr(), ws.data_ptr(), _s()), "cor_similarity_topk")
+        finally:
+            lib.cor_topk_set_mode(0)
     return scores, idx

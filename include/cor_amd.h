@@ -161,7 +161,12 @@ int cor_iou_select(const float* iou, const float* hyper, int B, int Kall, int k_
  * (score desc, index asc); indices are returned as global ids (g + g_offset).
  * Q [Bq,C] fp32, G [Ng,C] in g_dtype (COR_F32 exact chain / COR_BF16 / COR_F16), C <= 256 and C % 16 == 0, k <= 32;
  * missing entries (Ng < k) come back as score -inf, index -1. workspace >= cor_topk_workspace_bytes(Bq,Ng,k).
- * The reference has no gallery/top-k code; the definition follows utils/loss_func.py:84 (cosine of unit vectors). */
+ * The reference has no gallery/top-k code; the definition follows utils/loss_func.py:84 (cosine of unit vectors).
+ * 16-bit shards of >= 32768 rows use threshold-and-append (a dense sample pass bounds each query's k-th best score,
+ * the full pass appends the rare scores above it, exact selection over the candidates); if a query's candidate list
+ * overflows (pathological score distributions) ALL its indices come back as -2: call cor_topk_set_mode(1) (per-lane
+ * list kernels, always exact) and repeat. */
+int cor_topk_set_mode(int force_lists);
 long cor_topk_workspace_bytes(int Bq, int Ng, int k);
 int cor_similarity_topk(const float* Q, const void* G, int g_dtype, int Bq, int Ng, int C, int k, long long g_offset,
                         float* out_scores, long long* out_idx, void* workspace, void* stream);

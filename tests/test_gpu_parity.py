@@ -460,7 +460,7 @@ def test_siglip_towers_vs_oracle():
 # ======================================================================================================
 # retrieval
 # ======================================================================================================
-@pytest.mark.parametrize("Bq,Ng,k", [(4, 1000, 5), (32, 10000, 10), (7, 37, 32), (64, 4097, 1)])
+@pytest.mark.parametrize("Bq,Ng,k", [(4, 1000, 5), (32, 10000, 10), (7, 37, 32), (64, 4097, 1), (300, 20011, 10), (512, 3000, 16), (64, 40000, 10), (300, 70001, 5)])
 @pytest.mark.parametrize("gdt", [F32, BF16, torch.float16])
 def test_similarity_topk(Bq, Ng, k, gdt):
     ops, _ = _ops()
@@ -499,3 +499,17 @@ def test_similarity_topk_fp32_bitwise_vs_fma_chain_oracle(Bq, Ng, k):
     rs, ri = oret.similarity_topk(Q, G, k, exact_chain=True)
     assert torch.equal(i.cpu(), ri), "top-k indices differ from the bit-exact oracle"
     assert torch.equal(s.cpu().view(torch.int32), rs.view(torch.int32)), "scores are not bit-identical"
+
+
+def test_similarity_topk_candidate_overflow_falls_back_to_exact_lists():
+    """A degenerate gallery (every row identical => every score ties with the sample threshold) overflows the
+    threshold-and-append candidate lists; the wrapper must detect the -2 marker and re-run the exact list kernels."""
+    ops, _ = _ops()
+    rng = np.random.default_rng(5)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((40, 256), dtype=np.float32)), dim=-1)
+    row = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((1, 256), dtype=np.float32)), dim=-1)
+    G = row.repeat(50000, 1).to(BF16)
+    s, i = ops.similarity_topk(Q.to(DEV), G.to(DEV), 10)
+    assert torch.equal(i.cpu(), torch.arange(10).repeat(40, 1)), i[:2]
+    _, raw = ops.similarity_topk(Q.to(DEV), G.to(DEV), 10, check_overflow=False)
+    assert (raw == -2).all()
