@@ -44,6 +44,9 @@ SIGNATURES = {
     "cor_upscale_shuffle": [_p, _i, _p, _p, _p, _f, _i, _p, _i, _i, _i, _i, _i, _p],
     "cor_upscale_hyper": [_p, _i, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _p],
     "cor_iou_select": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "cor_mask_prob_minmax": [_p, _p, _i, _i, _p],
+    "cor_resize_binarize": [_p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cor_mask_metrics": [_p, _p, _p, _i, _i, _f, _p],
     "cor_topk_set_mode": [_i],
     "cor_topk_workspace_bytes": [_i, _i, _i],
     "cor_similarity_topk": [_p, _p, _i, _i, _i, _i, _i, _ll, _p, _p, _p, _p],

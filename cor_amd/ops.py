@@ -366,3 +366,35 @@ def similarity_topk(Q, G, k, g_offset=0, check_overflow=True):
         finally:
             lib.cor_topk_set_mode(0)
     return scores, idx
+
+
+def mask_prob_minmax(logits):
+    """sigmoid + per-sample min-max normalisation of mask logits [B,1,H,W] (utils/vailder.py:426-430)."""
+    _dev(logits)
+    x = logits.to(torch.float32).contiguous()
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    nat.check(_lib().cor_mask_prob_minmax(x.data_ptr(), out.data_ptr(), B, x.numel() // B, _s()), "cor_mask_prob_minmax")
+    return out
+
+
+def resize_binarize(prob, OH, OW, threshold=0.5):
+    """[B,1,H,W] probabilities -> uint8 {0,255} [B,OH,OW] (cv2.INTER_LINEAR semantics, utils/vailder.py:459-473)."""
+    _dev(prob)
+    assert prob.dtype == torch.float32 and prob.is_contiguous()
+    B, H, W = prob.shape[0], prob.shape[-2], prob.shape[-1]
+    assert prob.numel() == B * H * W
+    out = torch.empty((B, OH, OW), dtype=torch.uint8, device=prob.device)
+    nat.check(_lib().cor_resize_binarize(prob.data_ptr(), out.data_ptr(), B, H, W, OH, OW, float(threshold), _s()), "cor_resize_binarize")
+    return out
+
+
+def mask_metrics(pred, gt, smooth=1e-5):
+    """per-sample [dice, mae, iou, mdice, miou] (utils/trainer_v3_g.py:381-443). pred, gt: [B,...] fp32 of equal shape."""
+    _dev(pred, gt)
+    assert pred.shape == gt.shape, f"Shape mismatch: pred {tuple(pred.shape)} vs gt {tuple(gt.shape)}"
+    p, g = pred.to(torch.float32).contiguous(), gt.to(torch.float32).contiguous()
+    B = p.shape[0]
+    out = torch.empty((B, 5), dtype=torch.float32, device=p.device)
+    nat.check(_lib().cor_mask_metrics(p.data_ptr(), g.data_ptr(), out.data_ptr(), B, p.numel() // B, float(smooth), _s()), "cor_mask_metrics")
+    return out

@@ -89,3 +89,47 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
     dist.all_gather(s_parts, s, group=group)                     # 12 B * B_total * k per rank
     dist.all_gather(i_parts, i, group=group)
     return merge_topk_host([t.cpu() for t in s_parts], [t.cpu() for t in i_parts], k)
+
+
+@torch.no_grad()
+def build_gallery(model, batches, dtype=torch.float16):
+    """Offline gallery builder: SAM image encoder over gallery images + region mask pooling
+    (utils/loss_func.py:35-56) -> unit-norm rows [G, 256] in `dtype`, in input order.
+    `batches` yields dicts with "query_img" f32[B,3,1024,1024] and "query_mask" f32[B,1,h,w] (the reference's loader
+    field names, utils/dataloader.py:244-369). Only the encoder half of the forward runs (engine.sam_encoder)."""
+    from . import engine
+    rows = []
+    T = model._resolve_dtype()
+    W = model.packed(T)
+    cfg = model.image_encoder.cfg
+    g = cfg["img"] // cfg["patch"]
+    for b in batches:
+        img = b["query_img"].to(model.device, torch.float32).contiguous()
+        B = img.shape[0]
+        tok = engine.sam_encoder(W, img, cfg, T)                                       # [B*g*g, 256] fp32 tokens
+        m = b["query_mask"].to(model.device, torch.float32).contiguous()
+        if tuple(m.shape[-2:]) != (g, g):
+            m = ops.bilinear(m, g, g)
+        # tokens are channels-last: pool them directly (feat_nchw=False), clamp + L2-normalise as mask_pooling does
+        rows.append(ops.masked_pool(tok, m, B, g * g, cfg["out"], feat_nchw=False, clamp01=True, l2norm=True).to(dtype))
+    return torch.cat(rows, dim=0)
+
+
+def save_gallery(path, rows, world=1):
+    """On-disk format: <path>.shardNN.pt (rows of shard NN as a tensor) + <path>.manifest.json (row ranges)."""
+    import json
+    n = rows.shape[0]
+    shards = []
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        torch.save(rows[lo:hi].cpu().contiguous(), f"{path}.shard{r:02d}.pt")
+        shards.append(dict(rank=r, lo=lo, hi=hi, file=f"{path}.shard{r:02d}.pt"))
+    with open(f"{path}.manifest.json", "w") as f:
+        json.dump(dict(rows=n, dim=int(rows.shape[1]), dtype=str(rows.dtype), world=world, shards=shards), f, indent=1)
+
+
+def load_gallery_shard(path, rank, device):
+    import json
+    man = json.load(open(f"{path}.manifest.json"))
+    sh = man["shards"][rank]
+    return GalleryShard(torch.load(sh["file"]).to(device), offset=sh["lo"])

@@ -155,6 +155,19 @@ int cor_upscale_hyper(const void* x, int dtype, const float* w, const float* bia
 int cor_iou_select(const float* iou, const float* hyper, int B, int Kall, int k_off, int Ksel, int C, long long* best,
                    float* hyper_sel, void* stream);
 
+/* ---- inference harness (mask post-processing, metrics) ---------------------------------------------------------------- */
+
+/* out = (sigmoid(x) - min) / (max - min + 1e-8), min/max per sample. ref: utils/vailder.py:426-430. */
+int cor_mask_prob_minmax(const float* logits, float* out, int B, int HW, void* stream);
+
+/* Bilinear resize (half-pixel centres, edge clamp = cv2.INTER_LINEAR) of [B,H,W] probabilities to [B,OH,OW], then
+ * (> threshold) ? 255 : 0 as uint8. ref: utils/vailder.py:459-473. */
+int cor_resize_binarize(const float* prob, unsigned char* out, int B, int H, int W, int OH, int OW, float threshold, void* stream);
+
+/* out[b] = {dice, mae, iou, mdice, miou} of a soft prediction against the ground truth, [B,HW] each.
+ * ref: utils/trainer_v3_g.py:381-443 (compute_dice / compute_mae / compute_iou / compute_mdice / compute_miou). */
+int cor_mask_metrics(const float* pred, const float* gt, float* out, int B, int HW, float smooth, void* stream);
+
 /* ---- retrieval ------------------------------------------------------------------------------------------------ */
 
 /* Per query b: the top-k rows g of the gallery shard by score = q[b,:].G[g,:] (fp32 accumulate), ordered by

@@ -81,3 +81,18 @@ def postprocess_masks(logits, out_hw=None, threshold=0.5):
     if out_hw is not None:
         p = bilinear_resize(p, *out_hw)
     return ((p > threshold).to(torch.uint8) * 255), p
+
+
+def mask_metrics(pred, gt, smooth=1e-5):
+    """ref: utils/trainer_v3_g.py:381-443 -> [B,5] = dice, mae, iou, mdice, miou."""
+    p, g = pred.reshape(pred.shape[0], -1).float(), gt.reshape(gt.shape[0], -1).float()
+
+    def dice(a, b):
+        return (2.0 * (a * b).sum(1) + smooth) / (a.sum(1) + b.sum(1) + smooth)
+
+    def iou(a, b):
+        inter = (a * b).sum(1)
+        return (inter + smooth) / (a.sum(1) + b.sum(1) - inter + smooth)
+
+    return torch.stack([dice(p, g), (p - g).abs().mean(1), iou(p, g), 0.5 * (dice(p, g) + dice(1 - p, 1 - g)),
+                        0.5 * (iou(p, g) + iou(1 - p, 1 - g))], dim=1)

@@ -513,3 +513,90 @@ def test_similarity_topk_candidate_overflow_falls_back_to_exact_lists():
     assert torch.equal(i.cpu(), torch.arange(10).repeat(40, 1)), i[:2]
     _, raw = ops.similarity_topk(Q.to(DEV), G.to(DEV), 10, check_overflow=False)
     assert (raw == -2).all()
+
+
+# ======================================================================================================
+# inference harness: post-processing, metrics, save_hard_pred_masks / val_metric
+# ======================================================================================================
+def test_postprocess_resize_binarize_and_metrics_vs_oracle():
+    ops, _ = _ops()
+    rng = np.random.default_rng(8)
+    logits = torch.from_numpy(rng.standard_normal((3, 1, 256, 256), dtype=np.float32) * 3)
+    _, soft = oret.postprocess_masks(logits)
+    prob = ops.mask_prob_minmax(logits.to(DEV))
+    report("harness_prob_minmax", prob, soft, 1e-5, 1e-6)
+    for oh, ow in ((480, 640), (256, 256), (100, 77)):
+        hard = ops.resize_binarize(prob, oh, ow, 0.5)
+        ref_hard, _ = oret.postprocess_masks(logits, out_hw=(oh, ow))
+        diff = (hard.cpu() != ref_hard[:, 0]).float().mean().item()
+        assert diff <= 2e-5, f"binarised masks differ on {diff:.2e} of the pixels at {(oh, ow)}"   # only exact-0.5 crossings
+    gt = torch.from_numpy((rng.random((3, 1, 256, 256)) > 0.6).astype(np.float32))
+    report("harness_metrics", ops.mask_metrics(prob, gt.to(DEV)), oret.mask_metrics(soft, gt), 1e-4, 1e-6)
+
+
+def test_harness_save_hard_pred_masks_and_val_metric(tmp_path):
+    """End-to-end harness loop on the GPU with a stub model that returns fixed logits: PNG files (name, size, content)
+    and the metrics CSV must match the oracle's post-processing."""
+    import logging
+    from types import SimpleNamespace
+    from PIL import Image
+    from cor_amd import harness
+    rng = np.random.default_rng(9)
+    logits = torch.from_numpy(rng.standard_normal((2, 1, 256, 256), dtype=np.float32) * 2)
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+        def forward(self, **kw):
+            return logits.to(self.w.device), None, None
+
+    root = tmp_path / "data"
+    (root / "dsA" / "mask" / "7").mkdir(parents=True)
+    sizes = [(320, 200), (123, 456)]                     # PIL size = (W, H)
+    gts = []
+    for i, (w, h) in enumerate(sizes):
+        g = (rng.random((h, w)) > 0.5).astype(np.uint8) * 255
+        Image.fromarray(g).save(root / "dsA" / "mask" / "7" / f"m{i}.png")
+        gts.append(g)
+    batch = dict(query_img=torch.zeros(2, 3, 8, 8), support_img=torch.zeros(2, 3, 8, 8), support_mask=torch.zeros(2, 1, 8, 8),
+                 text=torch.ones(2, 64, dtype=torch.long), pair_id=[11, 12], query_mask_name=["m0.png", "m1.png"],
+                 dataset=["dsA", "dsA"], target=[7, 7], query_mask=(torch.from_numpy(rng.random((2, 1, 256, 256))) > 0.5).float(),
+                 compose=[0, 1], query_cat=[3, 4])
+    opt = SimpleNamespace(vaild_model_save_path=str(tmp_path / "out"), multimask_output=True)
+    log = logging.getLogger("harness-test")
+    model = Stub().to(DEV)
+    harness.save_hard_pred_masks([batch], model, opt, log, None, dataset_path=str(root), pred_save_dir="pred")
+    for i, (w, h) in enumerate(sizes):
+        got = np.array(Image.open(tmp_path / "out" / "pred" / f"{11 + i}_m{i}.png"))
+        ref, _ = oret.postprocess_masks(logits[i:i + 1], out_hw=(h, w))
+        assert got.shape == (h, w) and got.dtype == np.uint8
+        assert (got != ref[0, 0].numpy()).mean() <= 2e-5
+    res = harness.val_metric([batch], model, opt, log, None)
+    _, soft = oret.postprocess_masks(logits)
+    ref_m = oret.mask_metrics(soft, batch["query_mask"]).mean(0)
+    got_m = res["global_metrics"]
+    for k, j in (("dice", 0), ("mae", 1), ("iou", 2), ("mdice", 3), ("miou", 4)):
+        assert abs(got_m[k] - ref_m[j].item()) < 1e-4, (k, got_m[k], ref_m[j].item())
+    rows = list(__import__("csv").DictReader(open(tmp_path / "out" / "per_sample_metrics.csv")))
+    assert len(rows) == 2 and rows[0]["Id"] == "11" and rows[1]["Query_mask"] == "m1.png"
+
+
+def test_gallery_builder_and_checkpoint_loader(tmp_path):
+    """CORE-style checkpoint ("model_state_dict", "module." prefix) loads strictly; the gallery
+    builder's rows equal loss_func.mask_pooling of the oracle's SAM embeddings; shards round-trip through disk."""
+    from cor_amd import config, harness, retrieval
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=1, t_depth=1, vocab=64)
+    model = _build(2, (1,), gcfg, "MaskedPooling")
+    sd = ocfg.random_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 61)
+    torch.save({"epoch": 3, "model_state_dict": {"module." + k: v for k, v in sd.items()}}, tmp_path / "ck.pth")
+    res, epoch = harness.load_core_checkpoint(model, str(tmp_path / "ck.pth"))
+    assert epoch == 3 and not res.missing_keys and not res.unexpected_keys
+    model = model.to(DEV).eval()
+    inp = make_inputs(62, q=(2, 3, 1024, 1024), m=("mask", 2, 256))
+    rows = retrieval.build_gallery(model, [dict(query_img=inp["q"], query_mask=inp["m"])], dtype=torch.float32)
+    ref = oret.region_embedding(osam.image_encoder(sd, inp["q"], dict(model.image_encoder.cfg)), inp["m"])[:, 0]
+    report("gallery_rows_vs_oracle", rows, ref, 1e-3, 1e-4)
+    retrieval.save_gallery(str(tmp_path / "gal"), rows.to(torch.float16), world=2)
+    sh = retrieval.load_gallery_shard(str(tmp_path / "gal"), 1, DEV)
+    assert sh.offset == 1 and len(sh) == 1 and torch.equal(sh.rows.cpu(), rows[1:2].to(torch.float16).cpu())
