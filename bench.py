@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=0, help="1: support branch on a second HIP stream (+4.5 % end to end; inflates per-kernel timings)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
     return ap.parse_args()
 
@@ -80,7 +81,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
-    from cor_amd import ops, retrieval, utils
+    from cor_amd import engine, ops, retrieval, utils
+    engine.OVERLAP_BRANCHES = bool(args.overlap)
     from cor_amd.lib.build_model import build_model_with_query_support_feat
 
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
