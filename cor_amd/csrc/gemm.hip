@@ -161,8 +161,9 @@ __device__ __forceinline__ void epilogue_vec(const f32x16 (&acc)[MI][NJ], float*
 //               image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE chunk and undone on the read;
 //               needs K bytes % 128 == 0.
 // GLDS = false: register-staged double buffering (handles a ragged K tail by zero fill).
-template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS>
-__global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {   // <= 256 VGPR+AGPR: 2 waves per SIMD
+template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS, int NBUF = 2>
+__global__ void __launch_bounds__(WM * WN * 64, ((BM / WM) * (BN / WN) >= 8192 && WM * WN == 4) ? 1 : 2)
+gemm_tile(const GemmArgs g) {   // <= 256 VGPR+AGPR (2 waves per SIMD) except the one-wave-per-SIMD 128x64-per-wave form
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NJ = WTN / 32;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, BUF = A_BYTES + B_BYTES;
@@ -245,6 +246,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {
   auto compute = [&](const char* buf) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // big wave tiles (8 accumulators = 128 VGPRs): keep hipcc from hoisting the fragment reads of all four K-sub-steps
+      // above the first MFMA (it did, and spilled 365 VGPRs); one scheduling fence per sub-step bounds the live fragments.
+      if constexpr (MI * NJ >= 8) __builtin_amdgcn_sched_barrier(0);
       uint4 af[MI], bf[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[i] = *(const uint4*)(buf + a_rd + i * 32 * ROWB + ch_rd[s]);
@@ -262,6 +266,27 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {
   // in flight under the MFMAs of tile t; each wave drains its own DMA (vmcnt(0)) just before the barrier that
   // publishes the buffer.
   auto dma_wait = [&]() { if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  if constexpr (GLDS && NBUF == 3) {
+    // three LDS buffers: the DMA of tile t+2 is issued while tile t is computed, so a copy has TWO K-steps to land;
+    // a wave waits only until its own part of tile t is in (counted vmcnt leaves the newest tile's loads in flight).
+    constexpr int LPT = ACH + BCH;
+    static_assert(LPT == 6 || LPT == 8 || LPT == 12, "counted wait literals below");
+    stage_issue(0, 0);
+    if (nkt > 1) stage_issue(1, 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) {
+        if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (LPT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();                                 // tile kt visible to all; everyone is done with tile kt-1
+      if (kt + 2 < nkt) stage_issue(kt + 2, (kt + 2) % 3);
+      compute(smem + (kt % 3) * BUF);
+    }
+    __syncthreads();                                   // staging below reuses the buffers
+  } else {
   stage_issue(0, 0);
   stage_commit(0);
   dma_wait();
@@ -278,6 +303,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) gemm_tile(const GemmArgs g) {
     if (kt + 2 < nkt) stage_commit(0);
     dma_wait();
     __syncthreads();
+  }
   }
 
   // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane owns
@@ -638,16 +664,16 @@ __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, cons
 
 int g_gemm_cfg = 0, g_gemm_dbg = 0;   // 0 = auto; 1..6 force a tile configuration (tools/gemm_bench.py)
 
-template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS>
+template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS, int NBUF = 2>
 int launch_tile(GemmArgs g, hipStream_t s) {
-  constexpr int LDS = 2 * (BM + BN) * ROWB;
+  constexpr int LDS = NBUF * (BM + BN) * ROWB;
   g.tm = cdiv(g.M, BM); g.tn = cdiv(g.N, BN);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tile<TA, TO, BM, BN, WM, WN, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tile<TA, TO, BM, BN, WM, WN, GLDS, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_tile<TA, TO, BM, BN, WM, WN, GLDS>), dim3(g.tm * g.tn), dim3(WM * WN * 64), LDS, s, g);
+  hipLaunchKernelGGL((gemm_tile<TA, TO, BM, BN, WM, WN, GLDS, NBUF>), dim3(g.tm * g.tn), dim3(WM * WN * 64), LDS, s, g);
   COR_CHECK_LAUNCH();
   return 0;
 }
@@ -677,8 +703,8 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
               (!residual || (al16(residual) && ldr % 4 == 0));
   const bool k128 = g.Kb % ROWB == 0;                 // direct-to-LDS staging cannot zero-fill a K tail
   int cfg = g_gemm_cfg;
-  if (cfg == 0) cfg = (k128 && M >= 512 && N >= 64) ? COR_GEMM_DEFAULT_BIG : 1;
-  if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
+  if (cfg == 0) cfg = (k128 && M >= 512 && N >= 64) ? ((N <= 256 && K >= 2048 && M >= 65536) ? 9 : COR_GEMM_DEFAULT_BIG) : 1;
+  if (!k128 && cfg == 2) cfg = 1;
   if (cfg == 7) {
     if (!k128) cfg = 1;
     else {
@@ -716,12 +742,10 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     }
     if (!k128) cfg = 1;
   }
+  if (!k128 && cfg >= 9) cfg = 1;
   switch (cfg) {
+    case 9: return launch_tile<TA, TO, 256, 128, 4, 2, true, 3>(g, s);
     case 2: return launch_tile<TA, TO, 128, 128, 2, 2, true>(g, s);
-    case 3: return launch_tile<TA, TO, 256, 128, 4, 2, true>(g, s);
-    case 4: return launch_tile<TA, TO, 256, 256, 2, 4, true>(g, s);
-    case 5: return launch_tile<TA, TO, 256, 128, 4, 2, false>(g, s);
-    case 6: return launch_tile<TA, TO, 256, 256, 2, 4, false>(g, s);
     default: return launch_tile<TA, TO, 128, 128, 2, 2, false>(g, s);
   }
 }
@@ -730,7 +754,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
 
 extern "C" int cor_gemm_set_config(int cfg) {
   if (cfg >= 100) { g_gemm_dbg = cfg - 100; return 0; }            // timing-only ablation knobs (persistent kernel)
-  if (cfg < 0 || cfg > 8) return COR_EINVAL;
+  if (cfg < 0 || cfg > 12) return COR_EINVAL;
   g_gemm_cfg = cfg;
   return 0;
 }

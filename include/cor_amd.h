@@ -42,8 +42,9 @@ int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype,
              const float* bias, int act, const float* col_scale,
              const float* residual, long ldr, int res_row_mod, void* stream);
 
-/* Tuning knob for tools/gemm_bench.py: 0 = automatic tile choice (default), 1..6 force one tile configuration
- * (1: 128x128 reg-staged, 2: 128x128 direct-to-LDS, 3/5: 256x128 LDS-DMA/reg, 4/6: 256x256 LDS-DMA/reg). */
+/* Tuning knob for tools/gemm_bench.py: 0 = automatic choice (default); 1: 128x128 register-staged (any K);
+ * 2: 128x128 LDS-DMA (default for big shapes); 7: persistent 128x128 with cross-tile prefetch; 8: 128x128 on 16x16x32
+ * MFMA; 9: 256x128, three LDS buffers. Values >= 100 set timing-only ablation / tile-order knobs (tools/). */
 int cor_gemm_set_config(int cfg);
 
 /* y[r,:] = LayerNorm(x[r,:]) * w + b over the last dim, biased variance.
