@@ -25,6 +25,7 @@ SIGNATURES = {
     "cor_layernorm": [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p],
     "cor_attention": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p, _l, _l, _i, _i, _i, _i, _i, _i, _f, _p],
     "cor_sam_attention": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "cor_flash_set_variant": [_i],
     "cor_patchify": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cor_im2col3x3": [_p, _i, _p, _i, _i, _i, _i, _p],
     "cor_add": [_p, _i, _p, _i, _p, _i, _l, _l, _p],

@@ -364,6 +364,243 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Global SAM attention, 64 queries per wave (two 32-query blocks), ONE wave per SIMD (block = 4 waves = 256 queries).
+// Every K fragment (ds_read_b128) and every transposed V fragment (2 x ds_read_b64_tr_b16) now feeds TWO MFMAs, which
+// halves LDS traffic and barriers per flop, and the two query blocks give each wave two independent MFMA->softmax->MFMA
+// chains, so the matrix pipe works on one block while the VALU runs the other block's softmax (with 32 queries per wave
+// the loop was barrier/latency bound: MFMA busy 25 %, waves waiting 54 % of their cycles). Needs ~300 registers, hence
+// one wave per SIMD; LDS = 32 KiB K/V double buffer + 4 x 16 KiB row-bias tables.
+template <typename TO>
+__global__ void __launch_bounds__(256, 1) flash_global64(const FlashArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int QB = 2, AUX64 = 2 * AUX_PER_WAVE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
+  const int head = hb_ % a.H, b = hb_ / a.H;
+  const int S = a.S;                                   // 64
+  const int g2 = a.grid * a.grid;
+  const bf16_t* kvbase = a.q + (long)b * g2 * a.d3 + head * 64;
+
+  int qh[QB], qw[QB]; long orow[QB]; bool qvalid[QB];
+  uint4 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int tq = qt_ * 256 + wave * 64 + qb * 32 + r;
+    qvalid[qb] = tq < a.Tq;
+    tq = min(tq, a.Tq - 1);
+    qh[qb] = tq / S; qw[qb] = tq - qh[qb] * S;
+    orow[qb] = (long)b * g2 + tq;
+    const bf16_t* qp = a.q + orow[qb] * a.d3 + head * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[qb][c] = *(const uint4*)(qp + 16 * c + 8 * h);
+  }
+
+  // ---- relative-position tables (log2 domain): Th part -> aux[kh][qb*32 + q], Tw part -> registers
+  float* aux = (float*)(smem + KV_BYTES + wave * AUX64);
+  float* scr = (float*)(smem + wave * AUX_PER_WAVE);   // aliases the K/V buffers: barrier before staging
+  float wreg[QB][2][16];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll 1
+    for (int tbl = 0; tbl < 2; ++tbl) {
+      const float* table = tbl == 0 ? a.rel_h : a.rel_w;
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
+          const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
+                                                              __builtin_bit_cast(bf16x8, qf[qb][c]), acc[jb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * LOG2E;
+        if (tbl == 0) {
+#pragma unroll 4
+          for (int i = 0; i < 32; ++i) {
+            const int kh = 32 * h + i, j = qh[qb] + (S - 1) - kh;
+            if ((j >> 6) == half) aux[kh * 64 + qb * 32 + r] = scr[(j & 63) * 32 + r];
+          }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int kw = kb * 32 + acc_row(e, h), j = qw[qb] + (S - 1) - kw;
+              if ((j >> 6) == half) wreg[qb][kb][e] = scr[(j & 63) * 32 + r];
+            }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- staging (register-staged double buffering, as flash_fwd)
+  const int srow = tid >> 3, sch = tid & 7;
+  const int k_st0 = srow * 128 + ((sch ^ ((srow >> 1) & 7)) << 4);
+  const int k_st1 = (srow + 32) * 128 + ((sch ^ (((srow + 32) >> 1) & 7)) << 4);
+  const int v_st0 = srow * 128 + sch * 16, v_st1 = (srow + 32) * 128 + sch * 16;
+  uint4 rk0, rk1, rv0, rv1;
+#define G64_GLOAD(T_)                                                                              \
+  {                                                                                                \
+    const bf16_t* p0_ = kvbase + (long)((T_) * KT + srow) * a.d3 + sch * 8;                        \
+    const bf16_t* p1_ = p0_ + 32L * a.d3;                                                          \
+    rk0 = *(const uint4*)(p0_ + a.H * 64); rv0 = *(const uint4*)(p0_ + 2 * a.H * 64);             \
+    rk1 = *(const uint4*)(p1_ + a.H * 64); rv1 = *(const uint4*)(p1_ + 2 * a.H * 64);             \
+  }
+#define G64_LSTORE(BUF_)                                                                           \
+  {                                                                                                \
+    char* Ks_ = smem + (BUF_) * 2 * TILE_B; char* Vs_ = Ks_ + TILE_B;                              \
+    *(uint4*)(Ks_ + k_st0) = rk0; *(uint4*)(Ks_ + k_st1) = rk1;                                    \
+    *(uint4*)(Vs_ + v_st0) = rv0; *(uint4*)(Vs_ + v_st1) = rv1;                                    \
+  }
+  const int sw = (lane >> 1) & 7;
+  int kch[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kch[c] = r * 128 + (((2 * c + h) ^ sw) << 4);
+  const int v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  f32x16 o[QB][2];
+  float m[QB], l[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m[qb] = -INFINITY; l[qb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][db][e] = 0.f;
+  }
+  const int nt = a.Tk / KT;                            // 4096 / 64, no tail
+  G64_GLOAD(0)
+  G64_LSTORE(0)
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const bool more = t + 1 < nt;
+    if (more) G64_GLOAD(t + 1)
+    const char* Ks = smem + (t & 1) * 2 * TILE_B; const char* Vs = Ks + TILE_B;
+    // S^T = K . Q^T for both query blocks: one fragment read, two MFMAs
+    f32x16 s[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[qb][kb][e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 kf = *(const uint4*)(Ks + kb * 32 * 128 + kch[c]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[qb][c]), s[qb][kb], 0, 0, 0);
+      }
+    uint4 pf[QB][2][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float rh = aux[t * 64 + qb * 32 + r];
+      const f32x2_t sc2 = {a.scale_log2, a.scale_log2};
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          f32x2_t v = {s[qb][kb][e], s[qb][kb][e + 1]};
+          const f32x2_t w = {wreg[qb][kb][e], wreg[qb][kb][e + 1]};
+          v = v * sc2 + w;
+          s[qb][kb][e] = v[0]; s[qb][kb][e + 1] = v[1];
+          mloc = fmaxf(mloc, fmaxf(v[0], v[1]));
+        }
+      mloc = fmaxf(mloc, other_half(mloc)) + rh;
+      const float mnew = fmaxf(m[qb], mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);
+      const float msub = mnew - rh;
+      m[qb] = mnew;
+      l[qb] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[qb][db][e] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 p;
+        const f32x2_t ms2 = {msub, msub};
+        f32x2_t lacc = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2_t d = f32x2_t{s[qb][kb][e], s[qb][kb][e + 1]} - ms2;
+          const f32x2_t pe = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+          p[e] = pe[0]; p[e + 1] = pe[1];
+          lacc += pe;
+        }
+        l[qb] += lacc[0] + lacc[1];
+        pf[qb][kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+        pf[qb][kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
+      }
+    }
+    // O^T += V^T . P^T: one transposed fragment, two MFMAs
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int krow = kb * 32 + ks * 16;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* vb = Vs + krow * 128 + db * 64 + v_tr;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
+          const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+          const uint4 vf = make_uint4(u0.x, u0.y, u1.x, u1.y);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[qb][kb][ks]), o[qb][db], 0, 0, 0);
+        }
+      }
+    if (more) G64_LSTORE((t + 1) & 1)
+    __syncthreads();
+  }
+#undef G64_GLOAD
+#undef G64_LSTORE
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float lt = l[qb] + other_half(l[qb]);
+    if (!qvalid[qb]) continue;
+    const float inv = 1.0f / lt;
+    TO* op = (TO*)a.o + orow[qb] * (long)(a.H * 64) + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v4 = {o[qb][db][4 * g] * inv, o[qb][db][4 * g + 1] * inv, o[qb][db][4 * g + 2] * inv, o[qb][db][4 * g + 3] * inv};
+        st4<TO>(op + db * 32 + 8 * g + 4 * h, v4);
+      }
+  }
+}
+
+template <typename TO>
+int launch_global64(const FlashArgs& a, int nb, hipStream_t s) {
+  const size_t lds = KV_BYTES + 4 * 2 * AUX_PER_WAVE;  // 96 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)flash_global64<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  FlashArgs b = a;
+  b.nqt = cdiv(a.Tq, 256);
+  hipLaunchKernelGGL((flash_global64<TO>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int MODE, typename TO>
 int launch(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = KV_BYTES + (MODE == 0 ? 0 : 4 * AUX_PER_WAVE);
@@ -380,6 +617,9 @@ int launch(const FlashArgs& a, int nb, hipStream_t s) {
 }
 
 }  // namespace
+
+int g_flash_global_variant = 0;      // 0 (default): 32 queries per wave, 2 waves per SIMD (2.66 ms at B=32); 1: flash_global64 (3.37 ms: hipcc does not overlap the two chains)
+extern "C" int cor_flash_set_variant(int v) { g_flash_global_variant = v ? 1 : 0; return 0; }
 
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
@@ -405,6 +645,10 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   if (window == 0) {
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
+    if (g_flash_global_variant == 1) {
+      if (out_dtype == COR_BF16) return launch_global64<bf16_t>(a, B, s);
+      if (out_dtype == COR_F32) return launch_global64<float>(a, B, s);
+    }
     if (out_dtype == COR_BF16) return launch<1, bf16_t>(a, B, s);
     if (out_dtype == COR_F32) return launch<1, float>(a, B, s);
     return COR_ENOSUPPORT;

@@ -74,6 +74,9 @@ int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb,
 int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, const void* pad_row,
                       const float* rel_h, const float* rel_w, int B, int H, int hd, int grid, int window, void* stream);
 
+/* Tuning knob (tools/attn_bench.py): global SAM attention kernel form, 0 = 32 queries per wave (default), 1 = 64 per wave. */
+int cor_flash_set_variant(int v);
+
 /* ---- data movement / elementwise --------------------------------------------------------------------------- */
 
 /* Non-overlapping p x p patches of NCHW fp32 images -> rows [B*(H/p)*(W/p), Kpad] (k = c*p*p + dy*p + dx, zero

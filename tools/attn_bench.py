@@ -4,13 +4,14 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from cor_amd import ops
+from cor_amd import ops, _native
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 H, g, dev, T = 12, 64, "cuda:0", torch.bfloat16
 d = H * 64
 qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T)
 pad = torch.randn((3 * d,), device=dev).to(T)
-for window, S in ((0, 64), (14, 14)):
+for window, S, variant in ((0, 64, 0), (0, 64, 1), (14, 14, 1)):
+    _native.load().cor_flash_set_variant(variant)
     rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     ts = []
@@ -19,4 +20,4 @@ for window, S in ((0, 64), (14, 14)):
         e0.record(); ops.sam_attention(qkv, pad, rh, rw, B, H, g, window); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     fl = (4.0 * (g * g) ** 2 * 64 if window == 0 else 25 * 4.0 * 196 ** 2 * 64) * H * B
-    print(json.dumps(dict(window=window, B=B, ms=min(ts[1:]), tflops=fl / (min(ts[1:]) * 1e-3) / 1e12)), flush=True)
+    print(json.dumps(dict(window=window, variant=variant, B=B, ms=min(ts[1:]), tflops=fl / (min(ts[1:]) * 1e-3) / 1e12)), flush=True)
