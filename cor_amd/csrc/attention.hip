@@ -293,6 +293,7 @@ extern "C" int cor_attention(const void* q, long q_sb, long q_st, const void* k,
     case 32: return dispatch_types<32, 0>(a, B, dtype, out_dtype, s);
     case 64: return dispatch_types<64, 0>(a, B, dtype, out_dtype, s);
     case 72: return dispatch_types<72, 0>(a, B, dtype, out_dtype, s);
+    case 80: return dispatch_types<80, 0>(a, B, dtype, out_dtype, s);
     default: return COR_ENOSUPPORT;
   }
 }
@@ -327,6 +328,7 @@ extern "C" int cor_sam_attention(const void* qkv, int dtype, void* out, int out_
     case 16: return sam_rowlane<16>(a, B, grid, window, dtype, out_dtype, s);
     case 32: return sam_rowlane<32>(a, B, grid, window, dtype, out_dtype, s);
     case 64: return sam_rowlane<64>(a, B, grid, window, dtype, out_dtype, s);
+    case 80: return sam_rowlane<80>(a, B, grid, window, dtype, out_dtype, s);   // SAM ViT-H (1280 / 16 heads)
     default: return COR_ENOSUPPORT;
   }
 }

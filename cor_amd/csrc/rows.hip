@@ -275,7 +275,7 @@ extern "C" int cor_nchw_to_tokens(const float* x, void* out, int out_dtype, int 
 }
 
 extern "C" int cor_patchify(const float* img, void* out, int out_dtype, int B, int C, int H, int W, int p, int Kpad, void* stream) {
-  if (!img || !out || B <= 0 || C <= 0 || p <= 0 || H % p || W % p || Kpad < C * p * p || (Kpad & 3)) return COR_EINVAL;
+  if (!img || !out || B <= 0 || C <= 0 || p <= 0 || H < p || W < p || Kpad < C * p * p || (Kpad & 3)) return COR_EINVAL;
   const long total = (long)B * (H / p) * (W / p) * (Kpad >> 2);
   if (out_dtype == COR_F32) hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, (float*)out, B, C, H, W, p, Kpad);
   else if (out_dtype == COR_BF16) hipLaunchKernelGGL((patchify_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, B, C, H, W, p, Kpad);

@@ -39,8 +39,8 @@ class ImageEncoderViT(nn.Module):
     def __init__(self, img_size=1024, patch_size=16, embed_dim=768, depth=12, num_heads=12, out_chans=256,
                  window_size=14, global_attn_indexes: Tuple[int, ...] = ()):
         super().__init__()
-        if embed_dim // num_heads not in (16, 32, 64):
-            raise ValueError("cor_amd SAM attention kernels take head_dim 64 (all SAM sizes) or 16/32 (reduced test models)")
+        if embed_dim // num_heads not in (16, 32, 64, 80):
+            raise ValueError("cor_amd SAM attention kernels take head_dim 64 (SAM-B/L), 80 (SAM-H) or 16/32 (reduced test models)")
         self.img_size = img_size
         grid = img_size // patch_size
         self.cfg = dict(dim=embed_dim, depth=depth, heads=num_heads, global_idx=tuple(global_attn_indexes), window=window_size,

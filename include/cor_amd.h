@@ -56,7 +56,7 @@ int cor_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float*
 /* ---- attention -------------------------------------------------------------------------------------------- */
 
 /* out[b,t,h,:] = softmax_k(scale * q[b,t,h,:].k[b,k,h,:]) v ; element (b,t,h,c) of X lives at
- * X + b*x_sb + t*x_st + h*hd + c (strides in elements). hd in {16,32,64,72}.
+ * X + b*x_sb + t*x_st + h*hd + c (strides in elements). hd in {16,32,64,72,80}.
  * ref: lib/sam_model/transformer.py:218-240 (decoder Attention), SigLIP towers' MHA. */
 int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st,
                   const void* v, long v_sb, long v_st, int dtype,
@@ -64,7 +64,7 @@ int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb,
                   int B, int H, int Tq, int Tk, int hd, float scale, void* stream);
 
 /* SAM ViTDet attention on the fused qkv activation [B*grid*grid, 3*H*hd] (q|k|v, head-major inside each;
- * hd = 64 for every SAM size, 16/32 accepted for reduced test models):
+ * hd = 64 for SAM-B/L (bf16: MFMA flash kernels), 80 for SAM-H and 16/32 for reduced test models (row-per-lane kernel)):
  * logits = (q*hd^-0.5).k + q.Rh[qh-kh+S-1] + q.Rw[qw-kw+S-1] (rel-pos from the UNSCALED q).
  * window == 0: global attention over the grid (S = grid). window > 0: non-overlapping window x window tiles of the
  * grid zero-padded bottom/right to a multiple of `window` AFTER norm1, so a padded token's q/k/v equal the qkv
@@ -80,7 +80,8 @@ int cor_flash_set_variant(int v);
 /* ---- data movement / elementwise --------------------------------------------------------------------------- */
 
 /* Non-overlapping p x p patches of NCHW fp32 images -> rows [B*(H/p)*(W/p), Kpad] (k = c*p*p + dy*p + dx, zero
- * padded to Kpad), i.e. the A operand of the patch-embedding GEMM. ref: image_encoder.py:386-394. */
+ * padded to Kpad), i.e. the A operand of the patch-embedding GEMM; floor division: a ragged right/bottom border is
+ * dropped as a strided conv does (SO400M/14 at 384 px: 27x27 patches). ref: image_encoder.py:386-394. */
 int cor_patchify(const float* img, void* out, int out_dtype, int B, int C, int H, int W, int p, int Kpad, void* stream);
 
 /* 3x3, pad 1 im2col of channels-last tokens [B,H,W,C] -> [B*H*W, 9*C] (k = (ky*3+kx)*C + c).

@@ -38,7 +38,8 @@ def patch_tokens(x, w, b):
     x [B,3,H,W] -> [B, H/p, W/p, d]"""
     B, C, H, W = x.shape
     d, _, p, _ = w.shape
-    gh, gw = H // p, W // p
+    gh, gw = H // p, W // p                     # a strided conv drops the ragged border (SO400M/14 at 384: 27x27, 6 px unused)
+    x = x[:, :, :gh * p, :gw * p]
     cols = x.reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * p * p)
     return (cols @ w.reshape(d, -1).T + b).reshape(B, gh, gw, d)
 

@@ -187,7 +187,7 @@ def test_im2col3x3():
 # attention
 # ======================================================================================================
 @pytest.mark.parametrize("hd,H,Tq,Tk", [(16, 8, 6, 4096), (16, 8, 4096, 6), (32, 8, 6, 6), (64, 12, 576, 576), (64, 12, 64, 64),
-                                         (72, 16, 100, 729), (64, 2, 200, 333)])
+                                         (72, 16, 100, 729), (64, 2, 200, 333), (80, 2, 70, 130)])
 @pytest.mark.parametrize("T", [F32, BF16])
 def test_attention_plain(hd, H, Tq, Tk, T):
     ops, _ = _ops()
@@ -600,3 +600,72 @@ def test_gallery_builder_and_checkpoint_loader(tmp_path):
     retrieval.save_gallery(str(tmp_path / "gal"), rows.to(torch.float16), world=2)
     sh = retrieval.load_gallery_shard(str(tmp_path / "gal"), 1, DEV)
     assert sh.offset == 1 and len(sh) == 1 and torch.equal(sh.rows.cpu(), rows[1:2].to(torch.float16).cpu())
+
+
+# ======================================================================================================
+# other accepted model names and edge inputs
+# ======================================================================================================
+def _build_any(sam_dim, sam_heads, siglip_name, gcfg, pooling, depth=2, gidx=(1,)):
+    from cor_amd.lib.sam_model.image_encoder import ImageEncoderViT
+    from cor_amd.lib.sam_model.mask_decoder import MaskDecoder
+    from cor_amd.lib.sam_model.my_prompt_encoder import PromptEncoder
+    from cor_amd.lib.sam_model.transformer import TwoWayTransformer
+    from cor_amd.lib.sam_with_sup_branch import CirSegModelWithQuerySupportFeat
+    from cor_amd.lib.support_branch import SupportBranch
+    return CirSegModelWithQuerySupportFeat(
+        image_encoder=ImageEncoderViT(embed_dim=sam_dim, depth=depth, num_heads=sam_heads, global_attn_indexes=gidx),
+        support_branch=SupportBranch(siglip_name, None, pooling, siglip_cfg=gcfg),
+        prompt_encoder=PromptEncoder(256, (64, 64)),
+        mask_decoder=MaskDecoder(transformer_dim=256, transformer=TwoWayTransformer(2, 256, 8, 2048)))
+
+
+@pytest.mark.parametrize("sam_dim,sam_heads,siglip_name", [(1280, 16, "ViT-SO400M-14-SigLIP-384"), (1024, 16, "ViT-L-16-SigLIP2-384")])
+def test_other_model_sizes_vs_oracle(sam_dim, sam_heads, siglip_name):
+    """SAM-H width (head_dim 80) + SO400M/14 (27x27 tokens, head_dim 72, K = 588 / 4304: ragged GEMM K) and
+    SAM-L width + SigLIP2-L (tanh GELU), depth-reduced; fp32 exact mode against the oracle, bf16 mode sanity."""
+    from cor_amd import config
+    gcfg = dict(config.siglip_cfg(siglip_name), depth=1, t_depth=1, vocab=128)
+    model = _build_any(sam_dim, sam_heads, siglip_name, gcfg, "MaskAdapterPooling")
+    sd = ocfg.random_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 71)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    inp = make_inputs(72, q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 128), mask=("mask", 1, 384))
+    scfg = dict(model.image_encoder.cfg)
+    ref_emb = osam.image_encoder(sd, inp["q"], scfg)
+    ref_feat = osup.support_branch(sd, inp["s"], inp["text"], inp["mask"], gcfg, "MaskAdapterPooling")
+    ref_masks, ref_iou, _ = osam.mask_decoder(sd, ref_emb, osam.dense_pe(sd), ref_feat, osam.dense_no_mask(sd, 1), True)
+    kw = dict(query_image_inputs=inp["q"].to(DEV), support_image_inputs=inp["s"].to(DEV), change_text_inputs=inp["text"].to(DEV),
+              support_mask_inputs=inp["mask"].to(DEV))
+    masks, emb, feat, aux = model.forward_with_aux(**kw, multimask_output=True)
+    report(f"sizes_{sam_dim}_{siglip_name}_emb", emb, ref_emb, 1e-3, 2e-3)
+    report(f"sizes_{sam_dim}_{siglip_name}_feat", feat, ref_feat, 1e-3, 1e-4)
+    report(f"sizes_{sam_dim}_{siglip_name}_masks", aux["masks"][:, 1:], ref_masks, 2e-3, 5e-3)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, emb_b, feat_b = model(**kw, multimask_output=True)
+    report(f"sizes_{sam_dim}_{siglip_name}_emb_bf16", emb_b, ref_emb, 0, 4e-2 * ref_emb.abs().max().item())
+    report(f"sizes_{sam_dim}_{siglip_name}_feat_bf16", feat_b, ref_feat, 0, 3e-2)
+
+
+def test_edge_inputs_vs_oracle():
+    """B=3 (not a tile multiple), an all-zero support mask, an all-one mask, an all-pad text; MaskedPooling divides by
+    (sum + 1e-8) like the reference (mask_adapter.py:22)."""
+    from cor_amd import config
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=1, t_depth=1, vocab=64)
+    for pooling in ("MaskedPooling", "MaskAdapterPooling"):
+        model = _build(2, (1,), gcfg, pooling)
+        sd = ocfg.random_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 81)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).eval()
+        inp = make_inputs(82, q=(3, 3, 1024, 1024), s=(3, 3, 384, 384), text=("tokens", 3, 64, 64), mask=("mask", 3, 384))
+        inp["mask"][0] = 0.0
+        inp["mask"][1] = 1.0
+        inp["text"][2] = 1
+        scfg = dict(model.image_encoder.cfg)
+        ref_emb = osam.image_encoder(sd, inp["q"], scfg)
+        ref_feat = osup.support_branch(sd, inp["s"], inp["text"], inp["mask"], gcfg, pooling)
+        ref_masks, ref_iou, _ = osam.mask_decoder(sd, ref_emb, osam.dense_pe(sd), ref_feat, osam.dense_no_mask(sd, 3), False)
+        masks, emb, feat = model(query_image_inputs=inp["q"].to(DEV), support_image_inputs=inp["s"].to(DEV),
+                                 change_text_inputs=inp["text"].to(DEV), support_mask_inputs=inp["mask"].to(DEV), multimask_output=False)
+        report(f"edge_{pooling}_feat", feat, ref_feat, 1e-3, 1e-4)
+        report(f"edge_{pooling}_masks", masks, ref_masks, 2e-3, 5e-3)
+        assert torch.isfinite(masks).all() and torch.isfinite(feat).all()
