@@ -16,7 +16,11 @@ for mode in ("bf16_out", "f32_out_res"):
         act = 1 if mode.endswith("gelu") else 0
         row = dict(mode=mode, K=K)
         for c in cfgs:
-            if c >= 700:
+            if c >= 1300:
+                lib.cor_gemm_set_config(13); lib.cor_gemm_set_config(100 + c - 1300)
+            elif c >= 1200:
+                lib.cor_gemm_set_config(12); lib.cor_gemm_set_config(100 + c - 1200)
+            elif c >= 700:
                 lib.cor_gemm_set_config(7); lib.cor_gemm_set_config(100 + c - 700)
             else:
                 lib.cor_gemm_set_config(c); lib.cor_gemm_set_config(100)
