@@ -105,4 +105,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// Same copy, "saddr" form: wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: one VGPR per
+// address instead of two and no 64-bit VALU add per issue.
+__device__ __forceinline__ void glds16_so(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
