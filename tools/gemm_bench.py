@@ -18,6 +18,11 @@ SHAPES = [  # (M, N, K, act, residual, out_f32, label)
     (18432, 2304, 768, 0, False, False, "siglip qkv"),
     (18432, 3072, 768, 1, False, False, "siglip fc1+gelu"),
     (131072, 256, 2304, 0, False, True, "neck 3x3"),
+    (18432, 768, 768, 0, True, True, "siglip proj+res"),
+    (18432, 768, 3072, 0, True, True, "siglip fc2+res"),
+    (131072, 256, 768, 0, False, True, "neck 1x1"),
+    (2048, 2304, 768, 0, False, False, "text qkv"),
+    (8192, 1024, 1024, 0, True, True, "M=8192 square"),
 ]
 
 def main():

@@ -16,7 +16,9 @@ for mode in ("bf16_out", "f32_out_res"):
         act = 1 if mode.endswith("gelu") else 0
         row = dict(mode=mode, K=K)
         for c in cfgs:
-            if c >= 1300:
+            if c >= 1400:
+                lib.cor_gemm_set_config(14); lib.cor_gemm_set_config(100 + c - 1400)
+            elif c >= 1300:
                 lib.cor_gemm_set_config(13); lib.cor_gemm_set_config(100 + c - 1300)
             elif c >= 1200:
                 lib.cor_gemm_set_config(12); lib.cor_gemm_set_config(100 + c - 1200)
