@@ -11,14 +11,14 @@ def load(d, counter):
     f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and "gemm_tile<unsigned short" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and ("gemm_tile<unsigned short" in r["Kernel_Name"] or "gemm_pp<" in r["Kernel_Name"]):
             tot += float(r["Counter_Value"]); n += 1
     return tot, n
 
 fetch, n1 = load(sys.argv[1], "FETCH_SIZE")
 write, n2 = load(sys.argv[2], "WRITE_SIZE")
 assert n1 == n2 and n1 > 0
-out = dict(kernel="gemm_tile<bf16>", launches=n1, fetch_size_kib=fetch, write_size_kib=write,
+out = dict(kernel="bf16-operand GEMM kernels (gemm_pp<*>, gemm_tile<bf16,*>)", launches=n1, fetch_size_kib=fetch, write_size_kib=write,
            bytes_per_launch=(2.0 * fetch + write) * 1024.0 / n1,
            note="(2*FETCH_SIZE + WRITE_SIZE)*1024/launches; FETCH doubled per the gfx950 correction; includes Infinity-Cache hits")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
