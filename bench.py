@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=0, help="1: support branch on a second HIP stream (+4.5 % end to end; inflates per-kernel timings)")
+    ap.add_argument("--host-inputs", type=int, default=0, help="1: the batch starts in pinned host memory and is copied H2D inside every step "
+                    "(PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
     return ap.parse_args()
 
@@ -98,8 +100,11 @@ def main():
     rows = torch.nn.functional.normalize(torch.randn((Gtot, 256), generator=gen), dim=-1)[lo:hi]
     shard = retrieval.GalleryShard(rows.to(dev), offset=lo, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
 
+    host_batch = {k: v.cpu().pin_memory() for k, v in batch.items()} if args.host_inputs else None
+
     def step():
-        masks, emb, feat = model(**batch, multimask_output=True)
+        b = {k: v.to(dev, non_blocking=True) for k, v in host_batch.items()} if host_batch is not None else batch
+        masks, emb, feat = model(**b, multimask_output=True)
         return retrieval.distributed_search(feat[:, 0], shard, args.topk)
 
     def barrier():
@@ -144,7 +149,7 @@ def main():
         res = {
             "metric": "query triplets/sec (forward + similarity + top-k)", "value": world * B * args.steps / dt, "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.host_inputs else "synthetic, inputs copied from pinned host memory inside the step",
             "config": {"workload": f"{args.sam}+{args.siglip}+MaskAdapterPooling, {B} triplets/GPU, {Gtot}-row {args.dtype} gallery"
                                    + (f" sharded {world} ways (RCCL all-gather of queries, host top-k merge)" if world > 1 else ""),
                        "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
