@@ -47,6 +47,8 @@ SIGNATURES = {
     "cor_iou_select": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "cor_mask_prob_minmax": [_p, _p, _i, _i, _p],
     "cor_resize_binarize": [_p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cor_resample_rows_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "cor_resample_cols_u8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "cor_mask_metrics": [_p, _p, _p, _i, _i, _f, _p],
     "cor_topk_set_mode": [_i],
     "cor_topk_workspace_bytes": [_i, _i, _i],

@@ -173,6 +173,21 @@ int cor_resize_binarize(const float* prob, unsigned char* out, int B, int H, int
  * ref: utils/trainer_v3_g.py:381-443 (compute_dice / compute_mae / compute_iou / compute_mdice / compute_miou). */
 int cor_mask_metrics(const float* pred, const float* gt, float* out, int B, int HW, float smooth, void* stream);
 
+/* ---- input pre-processing (device side of utils/dataloader.py:266-293) ------------------------------------------------ */
+
+/* Pillow-BILINEAR resize of uint8 images, as torchvision.transforms.Resize performs it on a PIL image (Pillow
+ * src/libImaging/Resample.c, 8 bits per channel, antialiased on down-scaling), bit-exact. The caller supplies Pillow's
+ * fixed-point tables for one axis: bounds int32[out,2] = (first input index, tap count), kk int32[out,ksize] =
+ * int(0.5 + w * 2^22) (cor_amd/preprocess.py:resample_tables). Pass 1: rows. in u8[H,W,C] -> out u8[H,OW,C]; C in {1,3}. */
+int cor_resample_rows_u8(const unsigned char* in, unsigned char* out, const int* bounds, const int* kk, int ksize, int H, int W, int C,
+                         int OW, void* stream);
+
+/* Pass 2: columns of the uint8 image pass 1 produced, then ToTensor (+ Normalize): in u8[H,W,C] -> out_u8 u8[OH,W,C] (may be
+ * NULL) and out_f32 f32[C,OH,W] (may be NULL) = v/255, or (v/255 - mean[c]) / std[c] when mean/std are given (both or
+ * neither), in IEEE float32 exactly as torchvision's ToTensor / Normalize compute it. */
+int cor_resample_cols_u8(const unsigned char* in, float* out_f32, unsigned char* out_u8, const int* bounds, const int* kk, int ksize, int H,
+                         int W, int C, int OH, const float* mean, const float* stdv, void* stream);
+
 /* ---- retrieval ------------------------------------------------------------------------------------------------ */
 
 /* Per query b: the top-k rows g of the gallery shard by score = q[b,:].G[g,:] (fp32 accumulate), ordered by

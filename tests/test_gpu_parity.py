@@ -669,3 +669,45 @@ def test_edge_inputs_vs_oracle():
         report(f"edge_{pooling}_feat", feat, ref_feat, 1e-3, 1e-4)
         report(f"edge_{pooling}_masks", masks, ref_masks, 2e-3, 5e-3)
         assert torch.isfinite(masks).all() and torch.isfinite(feat).all()
+
+
+# ======================================================================================================
+# input pre-processing: Pillow-BILINEAR resize + ToTensor + Normalize, bit-exact
+# ======================================================================================================
+@pytest.mark.parametrize("h,w,c,size,norm", [(97, 131, 3, 24, True), (19, 23, 3, 48, True), (301, 457, 3, 384, True), (640, 480, 3, 1024, True),
+                                             (150, 111, 1, 32, False), (480, 640, 1, 384, False), (384, 384, 3, 384, True), (1024, 700, 3, 1024, True)])
+def test_preprocess_bit_exact_vs_oracle(h, w, c, size, norm):
+    """uint8 resize bit-identical to the oracle (itself pinned to Pillow); the float32 tensor bit-identical too (same IEEE ops:
+    v / 255, then (x - mean) / std). ref: utils/dataloader.py:266-293."""
+    from cor_amd import preprocess as CP
+    from oracle import preprocess as OP
+    rng = np.random.default_rng(h * 1000 + w)
+    a = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+    img = a if c == 3 else a[:, :, 0]
+    want_u8 = OP.resize_bilinear_u8(img, size, size)
+    want = OP.to_tensor_normalize(want_u8, OP.IMAGENET_MEAN if norm else None, OP.IMAGENET_STD if norm else None)
+    t = torch.from_numpy(img).to(DEV)
+    got, got_u8 = CP.resize_to_tensor(t, size, size, CP.IMAGENET_MEAN if norm else None, CP.IMAGENET_STD if norm else None, return_u8=True)
+    gu = got_u8.cpu().numpy()
+    assert np.array_equal(gu if c == 3 else gu[:, :, 0], want_u8)
+    assert got.shape == (c, size, size) and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_preprocess_golden_pillow_and_transforms():
+    """The committed Pillow outputs through the C ABI; the transform classes mirror the reference's Compose objects."""
+    import os
+    from cor_amd import preprocess as CP
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "preprocess_resize.npz"))
+    for k in d.files:
+        if not k.endswith("_in"):
+            continue
+        want = d[k[:-3] + "_out"]
+        _, u8 = CP.resize_to_tensor(torch.from_numpy(d[k]).to(DEV), want.shape[0], want.shape[1], return_u8=True)
+        u8 = u8.cpu().numpy()
+        assert np.array_equal(u8 if want.ndim == 3 else u8[:, :, 0], want), k
+    img = torch.randint(0, 256, (500, 375, 3), dtype=torch.uint8, device=DEV)
+    assert CP.QueryImageTransform()(img).shape == (3, 1024, 1024)
+    assert CP.ImageTransform(384)(img).shape == (3, 384, 384)
+    assert CP.MaskTransform(384)(img[:, :, 0].contiguous()).shape == (1, 384, 384)
+    with pytest.raises(RuntimeError):
+        CP.ImageTransform(384)(img.cpu())

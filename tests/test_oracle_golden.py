@@ -134,3 +134,42 @@ def test_state_dict_inventory_matches_reference():
     spec = ocfg.model_spec("sam_base", "ViT-B-16-SigLIP-384", "MaskedPooling")
     mine = sorted(k for k in spec if ".siglip." not in k)
     assert mine == keys
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# input pre-processing: the oracle's restatement of Pillow's BILINEAR resize vs Pillow's own output
+def test_preprocess_resize_matches_pillow_golden():
+    """tests/golden/preprocess_resize.npz was produced by Pillow itself (tools/make_golden_preprocess.py); the oracle must
+    reproduce it bit for bit, and the product's host tables (cor_amd.preprocess) must equal the oracle's."""
+    import os
+    from oracle import preprocess as OP
+    from cor_amd import preprocess as CP
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "preprocess_resize.npz"))
+    n = 0
+    for k in d.files:
+        if not k.endswith("_in"):
+            continue
+        want = d[k[:-3] + "_out"]
+        got = OP.resize_bilinear_u8(d[k], want.shape[0], want.shape[1])
+        assert got.dtype == np.uint8 and np.array_equal(got, want), k
+        n += 1
+    assert n >= 6
+    for i, o in [(131, 24), (23, 48), (600, 1024), (1500, 384), (384, 384), (7, 16)]:
+        b1, k1, s1 = OP.precompute_coeffs(i, o)
+        b2, k2, s2 = CP._tables_host(i, o)
+        assert s1 == s2 and np.array_equal(b1, b2) and np.array_equal(k1, k2)
+
+
+def test_preprocess_oracle_vs_live_pillow_full_size():
+    """Full-size property check against the installed Pillow (skipped where Pillow is absent): 1024 / 384 targets from odd sizes."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    from oracle import preprocess as OP
+    rng = np.random.default_rng(5)
+    for (h, w, c, s) in [(301, 457, 3, 384), (640, 480, 3, 1024), (480, 640, 1, 384)]:
+        a = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+        im = PIL_Image.fromarray(a if c == 3 else a[:, :, 0])
+        want = np.asarray(im.resize((s, s), PIL_Image.BILINEAR))
+        got = OP.resize_bilinear_u8(a if c == 3 else a[:, :, 0], s, s)
+        assert np.array_equal(got, want)
+    x = OP.preprocess_image(a[:, :, 0], 384, normalize=False)
+    assert x.shape == (1, 384, 384) and x.dtype == np.float32 and 0.0 <= x.min() and x.max() <= 1.0
