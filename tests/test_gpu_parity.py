@@ -125,6 +125,68 @@ def test_gemm_inplace_residual_and_strided_views():
     report("gemm_inplace_strided", x, ref, rtol=1e-4, atol=1e-4)
 
 
+# The persistent 256x256 ping-pong kernel (gemm_pp) is chosen for bf16 operands once the output has >= 200 tiles of 256x256:
+# none of the shapes above reach it, so it gets its own cases. K = 64 / 128 / 192 run one / two / three K-tiles (prologue-only,
+# first in-loop wait, steady state); M and N are ragged against 256; every case is also compared bit for bit with the 128x128
+# kernel (same accumulation order per k-step).
+@pytest.mark.parametrize("M,N,K", [(16645, 1032, 64), (16645, 1032, 128), (16645, 1032, 192), (12800, 1288, 576), (70000, 776, 320)])
+@pytest.mark.parametrize("mode", ["bf16", "bf16_gelu", "f32", "f32_res", "f32_res_inplace", "bf16_res_periodic", "bf16_gelu_tanh"])
+def test_gemm_pingpong(M, N, K, mode):
+    ops, _ = _ops()
+    from cor_amd import _native as nat
+    lib = nat.load()
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 200
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * N + 7 * K)
+    a = torch.randn((M, K), generator=g, device=DEV).to(BF16)
+    w = (torch.randn((N, K), generator=g, device=DEV) / math.sqrt(K)).to(BF16)
+    bias = torch.randn((N,), generator=g, device=DEV)
+    TO = BF16 if mode.startswith("bf16") else F32
+    act = 1 if mode == "bf16_gelu" else (4 if mode == "bf16_gelu_tanh" else 0)
+    period = 325 if mode == "bf16_res_periodic" else 0
+    res = None
+    if "res" in mode:
+        res = torch.randn((period or M, N), generator=g, device=DEV)
+    def run(cfg):
+        assert lib.cor_gemm_set_config(cfg) == 0
+        try:
+            if mode == "f32_res_inplace":
+                x = res.clone()
+                ops.gemm(a, w, out_dtype=F32, bias=bias, residual=x, out=x)
+                return x
+            return ops.gemm(a, w, out_dtype=TO, bias=bias, act=act, residual=res, res_row_mod=period)
+        finally:
+            lib.cor_gemm_set_config(0)
+    out = run(0)                                                   # auto: must pick the ping-pong kernel
+    out128 = run(2)
+    assert torch.equal(out, out128), f"ping-pong vs 128x128 kernel differ: {(out.float() - out128.float()).abs().max().item()}"
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (400,))]).to(DEV)   # both edges + a sample
+    z = a[rows].float() @ w.float().T + bias
+    if act == 1: z = torch.nn.functional.gelu(z)
+    if act == 4: z = torch.nn.functional.gelu(z, approximate="tanh")
+    if res is not None: z = z + (res[rows % period] if period else res[rows])
+    tol = dict(rtol=1e-4, atol=2e-4) if TO == F32 else dict(rtol=1e-2, atol=2e-2)
+    report(f"gemm_pp_{M}x{N}x{K}_{mode}", out[rows], z, **tol)
+
+
+def test_gemm_pingpong_guard_rows_and_fallbacks():
+    """The buffer-store epilogue must not touch rows around a C view; column-scaled / K % 64 != 0 GEMMs fall back to the 128x128 kernels."""
+    ops, _ = _ops()
+    M, N, K = 16500, 1040, 256
+    g = torch.Generator(device=DEV).manual_seed(1)
+    a = torch.randn((M, K), generator=g, device=DEV).to(BF16)
+    w = (torch.randn((N, K), generator=g, device=DEV) / 16).to(BF16)
+    for TO in (BF16, F32):
+        guard = torch.full((M + 2, N), 7.0, device=DEV, dtype=TO)
+        out = ops.gemm(a, w, out_dtype=TO, out=guard[1:M + 1])
+        assert bool((guard[0] == 7).all()) and bool((guard[M + 1] == 7).all())
+        report(f"gemm_pp_guard_{TO}", out[:256], a[:256].float() @ w.float().T, **(dict(rtol=1e-4, atol=2e-4) if TO == F32 else dict(rtol=1e-2, atol=2e-2)))
+    scale = torch.rand((N,), generator=g, device=DEV) + 0.5
+    out = ops.gemm(a, w, out_dtype=F32, col_scale=scale)
+    report("gemm_pp_fallback_colscale", out[:256], (a[:256].float() @ w.float().T) * scale, rtol=1e-4, atol=2e-4)
+    a2, w2 = a[:, :200].contiguous(), w[:, :200].contiguous()      # K = 200: not a multiple of 64
+    report("gemm_pp_fallback_ktail", ops.gemm(a2, w2, out_dtype=F32)[:256], a2[:256].float() @ w2.float().T, rtol=1e-4, atol=2e-4)
+
+
 # ======================================================================================================
 # row kernels
 # ======================================================================================================
