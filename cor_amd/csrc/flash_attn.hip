@@ -124,6 +124,32 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) qf[c] = *(const uint4*)(qp + 16 * c + 8 * h);
 
+  // ---- staging map. Windowed mode: a tile is 4 whole key rows of the 14x14 window (56 keys; LDS rows 56..63 are
+  // loaded but masked), so a score's (key row, key column) inside the tile is a compile-time property of its register.
+  constexpr int TSTRIDE = MODE == 2 ? 56 : KT;
+  const int srow = tid >> 3, sch = tid & 7;                 // rows srow and srow+32
+  const int k_st0 = srow * 128 + ((sch ^ ((srow >> 1) & 7)) << 4);
+  const int k_st1 = (srow + 32) * 128 + ((sch ^ (((srow + 32) >> 1) & 7)) << 4);
+  const int v_st0 = srow * 128 + sch * 16, v_st1 = (srow + 32) * 128 + sch * 16;
+  uint4 rk0, rk1, rv0, rv1;
+#define FA_GLOAD(T_)                                                                   \
+  {                                                                                    \
+    const bf16_t *kp_, *vp_;                                                           \
+    kv_src(min((T_) * TSTRIDE + srow, a.Tk - 1), kp_, vp_);                            \
+    rk0 = *(const uint4*)(kp_ + sch * 8); rv0 = *(const uint4*)(vp_ + sch * 8);        \
+    kv_src(min((T_) * TSTRIDE + srow + 32, a.Tk - 1), kp_, vp_);                       \
+    rk1 = *(const uint4*)(kp_ + sch * 8); rv1 = *(const uint4*)(vp_ + sch * 8);        \
+  }
+#define FA_LSTORE(BUF_)                                                                \
+  {                                                                                    \
+    char* Ks_ = smem + (BUF_) * 2 * TILE_B; char* Vs_ = Ks_ + TILE_B;                  \
+    *(uint4*)(Ks_ + k_st0) = rk0; *(uint4*)(Ks_ + k_st1) = rk1;                        \
+    *(uint4*)(Vs_ + v_st0) = rv0; *(uint4*)(Vs_ + v_st1) = rv1;                        \
+  }
+  // tile 0's global loads are issued here, before the rel-pos table work, so that their latency (~2 us, a fifth of a
+  // windowed block's lifetime) overlaps it; the registers are written to LDS after the tables (which alias the K/V buffers).
+  FA_GLOAD(0)
+
   // ---- relative-position tables (log2 domain)
   float* aux = (float*)(smem + KV_BYTES + wave * AUX_PER_WAVE);
   float wreg[2][16];
@@ -195,29 +221,6 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
         const int kw = loc - 14 * ((loc * 4682) >> 16);
         wreg[kb][e] = aux[1024 + (qw - kw + 13) * 32 + r];
       }
-  }
-
-  // ---- staging map. Windowed mode: a tile is 4 whole key rows of the 14x14 window (56 keys; LDS rows 56..63 are
-  // loaded but masked), so a score's (key row, key column) inside the tile is a compile-time property of its register.
-  constexpr int TSTRIDE = MODE == 2 ? 56 : KT;
-  const int srow = tid >> 3, sch = tid & 7;                 // rows srow and srow+32
-  const int k_st0 = srow * 128 + ((sch ^ ((srow >> 1) & 7)) << 4);
-  const int k_st1 = (srow + 32) * 128 + ((sch ^ (((srow + 32) >> 1) & 7)) << 4);
-  const int v_st0 = srow * 128 + sch * 16, v_st1 = (srow + 32) * 128 + sch * 16;
-  uint4 rk0, rk1, rv0, rv1;
-#define FA_GLOAD(T_)                                                                   \
-  {                                                                                    \
-    const bf16_t *kp_, *vp_;                                                           \
-    kv_src(min((T_) * TSTRIDE + srow, a.Tk - 1), kp_, vp_);                            \
-    rk0 = *(const uint4*)(kp_ + sch * 8); rv0 = *(const uint4*)(vp_ + sch * 8);        \
-    kv_src(min((T_) * TSTRIDE + srow + 32, a.Tk - 1), kp_, vp_);                       \
-    rk1 = *(const uint4*)(kp_ + sch * 8); rv1 = *(const uint4*)(vp_ + sch * 8);        \
-  }
-#define FA_LSTORE(BUF_)                                                                \
-  {                                                                                    \
-    char* Ks_ = smem + (BUF_) * 2 * TILE_B; char* Vs_ = Ks_ + TILE_B;                  \
-    *(uint4*)(Ks_ + k_st0) = rk0; *(uint4*)(Ks_ + k_st1) = rk1;                        \
-    *(uint4*)(Vs_ + v_st0) = rv0; *(uint4*)(Vs_ + v_st1) = rv1;                        \
   }
 
   // ---- fragment read maps
@@ -337,7 +340,6 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
     if (more) FA_LSTORE((t + 1) & 1)
     __syncthreads();
   };
-  FA_GLOAD(0)
   FA_LSTORE(0)
   __syncthreads();
   const int nfull = (a.Tk % TSTRIDE) ? nt - 1 : nt;

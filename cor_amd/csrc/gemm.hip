@@ -353,49 +353,62 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
                                                 int mbase, int nbase, int lane) {
   constexpr int VW = sizeof(TO) == 2 ? 8 : 4;
   constexpr int CV = 32 / VW, RPP = 64 / CV, PASS = 32 / RPP, Q4 = VW / 4;   // bf16: 4 lanes/row, 16 rows/pass, 2 passes
+  constexpr int NB = MI * NJ, D = (HAS_RES && sizeof(TO) == 4) ? 2 : 1;       // residual prefetch depth (4, or 2 with bf16 C: spills into the K loop)
   const int cv = lane % CV, row0 = lane / CV;
+  // Residual loads run D blocks ahead of their use (the K-loop fragment registers are free here): one block at a time, each
+  // block waited for its own HBM round trip and - VMEM retiring in order - for the previous block's stores, eight times per
+  // tile (20 us of a 42-us tile at K = 768 with an fp32 residual).
+  f32x4 res[D][PASS][Q4];
+  auto load_res = [&](int blk, f32x4 (&r)[PASS][Q4]) {
+    const int mi = blk / NJ, nj = blk % NJ;
+    const int n = nbase + nj * 32 + cv * VW;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int ps = 0; ps < PASS; ++ps) {
+      const int m = min(mbase + mi * 32 + ps * RPP + row0, g.M - 1);
+      const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-      const int n = nbase + nj * 32 + cv * VW;
-      f32x4 bv[Q4], res[PASS][Q4];                    // bias reloaded per block (L1 hit): 16 fewer live registers than hoisted
-#pragma unroll
-      for (int q4 = 0; q4 < Q4; ++q4) bv[q4] = g.bias ? *(const f32x4*)(g.bias + min(n + 4 * q4, g.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (HAS_RES) {
-#pragma unroll
-        for (int ps = 0; ps < PASS; ++ps) {
-          const int m = min(mbase + mi * 32 + ps * RPP + row0, g.M - 1);
-          const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
-#pragma unroll
-          for (int q4 = 0; q4 < Q4; ++q4) res[ps][q4] = *(const f32x4*)(g.residual + (long)rr * g.ldr + min(n + 4 * q4, g.N - 4));
-        }
-      }
-      fill(mi, nj, stg);                              // the wave's 32x32 block (mi, nj) -> stg[32][32]
-#pragma unroll
-      for (int ps = 0; ps < PASS; ++ps) {
-        const int row = ps * RPP + row0;
-        const int m = mbase + mi * 32 + row;
-        f32x4 v[Q4];
-#pragma unroll
-        for (int q4 = 0; q4 < Q4; ++q4) {
-          v[q4] = *(const f32x4*)(stg + row * 32 + cv * VW + 4 * q4) + bv[q4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT>(v[q4][q]);
-          if constexpr (HAS_RES) v[q4] += res[ps][q4];
-        }
-        // lanes outside C aim past num_records and are dropped by the buffer bounds check: no branch, fixed store count
-        const unsigned off = (m < g.M && n < g.N) ? (unsigned)(((long)m * g.ldc + n) * (long)sizeof(TO)) : 0xFFFFFFFFu;
-        u32x4 u;
-        if constexpr (VW == 8) {
-          u[0] = pack_bf16x2(v[0][0], v[0][1]); u[1] = pack_bf16x2(v[0][2], v[0][3]);
-          u[2] = pack_bf16x2(v[Q4 - 1][0], v[Q4 - 1][1]); u[3] = pack_bf16x2(v[Q4 - 1][2], v[Q4 - 1][3]);
-        } else {
-          u[0] = __float_as_uint(v[0][0]); u[1] = __float_as_uint(v[0][1]); u[2] = __float_as_uint(v[0][2]); u[3] = __float_as_uint(v[0][3]);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
-      }
+      for (int q4 = 0; q4 < Q4; ++q4) r[ps][q4] = *(const f32x4*)(g.residual + (long)rr * g.ldr + min(n + 4 * q4, g.N - 4));
     }
+  };
+  if constexpr (HAS_RES) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_res(d, res[d]);
+  }
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int mi = blk / NJ, nj = blk % NJ;
+    const int n = nbase + nj * 32 + cv * VW;
+    f32x4 bv[Q4];                                     // bias reloaded per block (L1 hit): 16 fewer live registers than hoisted
+#pragma unroll
+    for (int q4 = 0; q4 < Q4; ++q4) bv[q4] = g.bias ? *(const f32x4*)(g.bias + min(n + 4 * q4, g.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    fill(mi, nj, stg);                                // the wave's 32x32 block (mi, nj) -> stg[32][32]
+#pragma unroll
+    for (int ps = 0; ps < PASS; ++ps) {
+      const int row = ps * RPP + row0;
+      const int m = mbase + mi * 32 + row;
+      f32x4 v[Q4];
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; ++q4) {
+        v[q4] = *(const f32x4*)(stg + row * 32 + cv * VW + 4 * q4) + bv[q4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT>(v[q4][q]);
+        if constexpr (HAS_RES) v[q4] += res[blk % D][ps][q4];
+      }
+      // lanes outside C aim past num_records and are dropped by the buffer bounds check: no branch, fixed store count
+      const unsigned off = (m < g.M && n < g.N) ? (unsigned)(((long)m * g.ldc + n) * (long)sizeof(TO)) : 0xFFFFFFFFu;
+      u32x4 u;
+      if constexpr (VW == 8) {
+        u[0] = pack_bf16x2(v[0][0], v[0][1]); u[1] = pack_bf16x2(v[0][2], v[0][3]);
+        u[2] = pack_bf16x2(v[Q4 - 1][0], v[Q4 - 1][1]); u[3] = pack_bf16x2(v[Q4 - 1][2], v[Q4 - 1][3]);
+      } else {
+        u[0] = __float_as_uint(v[0][0]); u[1] = __float_as_uint(v[0][1]); u[2] = __float_as_uint(v[0][2]); u[3] = __float_as_uint(v[0][3]);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
+    }
+    if constexpr (HAS_RES) {
+      if (blk + D < NB) load_res(blk + D, res[blk % D]);
+    }
+  }
 }
 
 #define COR_VMCNT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")

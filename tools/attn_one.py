@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""One configuration of the SAM global attention kernel, a few launches (for rocprofv3 --pmc passes): python tools/attn_one.py <variant> [B]"""
+"""One configuration of the SAM attention kernels, a few launches (for rocprofv3 --pmc passes):
+python tools/attn_one.py <global_variant> [B] [window]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops, _native
-variant = int(sys.argv[1]); B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+variant = int(sys.argv[1]); B = int(sys.argv[2]) if len(sys.argv) > 2 else 32; window = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 H, g, dev, T = 12, 64, "cuda:0", torch.bfloat16
 d = H * 64
+S = 64 if window == 0 else 14
 qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T); pad = torch.randn((3 * d,), device=dev).to(T)
-rh = torch.randn((127, 64), device=dev) * 0.5; rw = torch.randn((127, 64), device=dev) * 0.5
+rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5; rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
 _native.load().cor_flash_set_variant(variant)
-for i in range(3): ops.sam_attention(qkv, pad, rh, rw, B, H, g, 0)
+for i in range(3): ops.sam_attention(qkv, pad, rh, rw, B, H, g, window)
 torch.cuda.synchronize()
