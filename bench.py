@@ -153,7 +153,7 @@ def main():
             "config": {"workload": f"{args.sam}+{args.siglip}+MaskAdapterPooling, {B} triplets/GPU, {Gtot}-row {args.dtype} gallery"
                                    + (f" sharded {world} ways (RCCL all-gather of queries, host top-k merge)" if world > 1 else ""),
                        "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_mfma<{args.dtype}>", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": ("cor_gemm, bf16 operands: gemm_pp<*> (persistent 256x256 ping-pong, >= 200 tiles) + gemm_tile<bf16,*,128,128> (the rest)" if args.dtype == "bf16" else "cor_gemm, fp32 operands: gemm_tile<float,float,128,128> on v_mfma_f32_32x32x2_f32"), "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, offline pass)",
                          "algorithmic_bytes_per_launch": gemm_bytes / max(n_launch, 1), "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
