@@ -42,9 +42,10 @@ int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype,
              const float* bias, int act, const float* col_scale,
              const float* residual, long ldr, int res_row_mod, void* stream);
 
-/* Tuning knob for tools/gemm_bench.py: 0 = automatic choice (default); 1: 128x128 register-staged (any K);
- * 2: 128x128 LDS-DMA (default for big shapes); 7: persistent 128x128 with cross-tile prefetch; 8: 128x128 on 16x16x32
- * MFMA; 9: 256x128, three LDS buffers. Values >= 100 set timing-only ablation / tile-order knobs (tools/). */
+/* Tuning knob for tools/gemm_bench.py: 0 = automatic choice (default: 13 for bf16 operands from 200 output tiles of 256x256
+ * up, else 2, or 1 when K has a ragged tail); 1: 128x128 register-staged (any K); 2: 128x128 LDS-DMA; 9: 256x128, three LDS
+ * buffers; 13: persistent 256x256 ping-pong kernel (bf16 operands; falls back to 2 / 1 where it does not apply); 14: the same
+ * on 16x16x32 MFMAs. Values >= 100 set timing-only ablation / tile-order knobs (tools/gemm_ksweep.py). */
 int cor_gemm_set_config(int cfg);
 
 /* y[r,:] = LayerNorm(x[r,:]) * w + b over the last dim, biased variance.
