@@ -236,7 +236,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
+  f32x16 lsum;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lsum[e] = 0.f;
+  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
 
   const int nt = (a.Tk + TSTRIDE - 1) / TSTRIDE;
   // one K/V tile; TAIL = the last, partially filled tile (the only one that needs per-key masking)
@@ -298,26 +302,26 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
         mloc = fmaxf(mloc, x);
       }
     mloc = fmaxf(mloc, other_half(mloc)) + rh;  // true tile max (x + rh)
-    const float mnew = fmaxf(m, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    const float msub = mnew - rh;                       // p = 2^(x + rh - mnew)
-    m = mnew;
-    l *= alpha;
+    // Lazy rescaling: the reference point m only moves when some row's tile max exceeds it by more than 8 (log2 domain), so
+    // p <= 256 and the 33 multiplies of the O / l rescale run a few times per row instead of once per tile; O / l is unchanged
+    // mathematically (same m in numerator and denominator). The softmax VALU, not the MFMA, bounds these kernels.
+    if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {
+      const float mnew = fmaxf(m, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      m = mnew;
+      lsum[0] *= alpha;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+    }
+    const float msub = m - rh;                          // p = 2^(x + rh - m)
     uint4 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 p;
-      float lacc0 = 0.f, lacc1 = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub); p[e + 1] = __builtin_amdgcn_exp2f(s[kb][e + 1] - msub);
-        lacc0 += p[e]; lacc1 += p[e + 1];
-      }
-      l += lacc0 + lacc1;
+      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
@@ -336,6 +340,9 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
           const uint4 vf = make_uint4(u0.x, u0.y, u1.x, u1.y);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
         }
+        // row sums of P on the matrix pipe: ones . P^T leaves sum_k P[k][q] (over the bf16-rounded P, as the numerator) in every
+        // row of lsum - 32 VALU adds per tile saved
+        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
       }
     if (more) FA_LSTORE((t + 1) & 1)
     __syncthreads();
@@ -346,9 +353,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < nt) tile(nt - 1, std::true_type{});
 
-  l += other_half(l);
   if (!qvalid) return;
-  const float inv = 1.0f / l;
+  const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
   TO* op = MODE == 0 ? (TO*)a.o + bz * a.o_sb + (long)tq * a.o_st + head * 64 : (TO*)a.o + orow * (long)(a.H * 64) + head * 64;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
