@@ -773,3 +773,48 @@ def test_preprocess_golden_pillow_and_transforms():
     assert CP.MaskTransform(384)(img[:, :, 0].contiguous()).shape == (1, 384, 384)
     with pytest.raises(RuntimeError):
         CP.ImageTransform(384)(img.cpu())
+
+
+# ======================================================================================================
+# BASELINE.json configs[1] at FULL size (SAM-B + SigLIP-B/16-384, batch 32) through size-independent properties
+# ======================================================================================================
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_full_size_batch_invariance_and_retrieval(mode):
+    """The oracle cannot run 32 full-size triplets in seconds, so the full configuration is checked through properties:
+    (1) batch invariance: every sample of a batch-32 forward (persistent 256x256 GEMM kernel, pipelined attention) equals, bit
+        for bit, the same sample run alone (batch 1: 128x128 GEMM kernels) - masks, image embeddings, fused features;
+    (2) comb_support_feat rows are unit vectors (support_branch.py:85);
+    (3) retrieval against a 10k-row gallery: sorted scores; sharding the gallery in two and merging on the host gives the
+        identical top-k (scores and indices bitwise); with an fp32 gallery the result is bitwise the CPU chain oracle's."""
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    from cor_amd import utils, retrieval
+    T = torch.bfloat16 if mode == "bf16" else torch.float32
+    B = 32 if mode == "bf16" else 8
+    model = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskAdapterPooling")
+    utils.randomize_parameters(model, seed=3)
+    model = model.to(DEV).eval()
+    model.compute_dtype = T
+    batch = utils.synthetic_batch(B, DEV, seed=11)
+    masks, emb, feat = model(**batch, multimask_output=True)
+    assert masks.shape == (B, 1, 256, 256) and emb.shape == (B, 256, 64, 64) and feat.shape == (B, 1, 256)
+    assert torch.isfinite(masks).all() and torch.isfinite(emb).all() and torch.isfinite(feat).all()
+    for i in (0, B // 2 + 1, B - 1):
+        one = {k: v[i:i + 1].contiguous() for k, v in batch.items()}
+        m1, e1, f1 = model(**one, multimask_output=True)
+        assert torch.equal(m1[0], masks[i]) and torch.equal(e1[0], emb[i]) and torch.equal(f1[0], feat[i]), f"sample {i} differs from its batch-1 run"
+    q = feat[:, 0]
+    assert torch.allclose(q.norm(dim=-1), torch.ones(B, device=DEV), atol=1e-5)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    rows = torch.nn.functional.normalize(torch.randn((10000, 256), generator=gen), dim=-1).to(DEV)
+    where = torch.arange(B, device=DEV) * 311 + 7
+    rows[where] = q                                  # (a random-init model's queries are nearly collinear: no self-match claim)
+    gdt = torch.float32 if mode == "f32" else torch.bfloat16
+    s_all, i_all = retrieval.GalleryShard(rows, 0, gdt).search(q, 10)
+    assert bool((s_all[:, :-1] >= s_all[:, 1:]).all())                       # sorted
+    if mode == "f32":                                                        # fp32 shards: bitwise the CPU chain oracle
+        rs, ri = oret.similarity_topk(q.cpu(), rows.cpu(), 10, exact_chain=True)
+        assert torch.equal(i_all.cpu(), ri) and torch.equal(s_all.cpu(), rs)
+    sa, ia = retrieval.GalleryShard(rows[:5000], 0, gdt).search(q, 10)
+    sb, ib = retrieval.GalleryShard(rows[5000:], 5000, gdt).search(q, 10)
+    sm, im = retrieval.merge_topk_host([sa.cpu(), sb.cpu()], [ia.cpu(), ib.cpu()], 10)
+    assert torch.equal(im, i_all.cpu()) and torch.equal(sm, s_all.cpu())
