@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Race screen for the hand-synchronised kernels (gemm_pp: counted vmcnt + barriers over a 10-slot LDS-DMA ring; flash_global_pipe:
+3-slot rings): many launches on fresh random data, every result compared bit for bit with the conservative kernel
+(cfg 2 / variant 0 within tolerance) - a rare early read of a staged buffer shows up as a sporadic mismatch.
+    python tools/race_screen.py [rounds=20]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from cor_amd import ops, _native
+lib = _native.load(); dev = "cuda:0"; T = torch.bfloat16
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+bad = 0
+shapes = [(16640, 1024, 64), (16640, 1024, 128), (16640, 1024, 192), (16640, 1024, 256), (32768, 768, 768), (20000, 1288, 3072), (131072, 768, 768)]
+for it in range(rounds):
+    for (M, N, K) in shapes:
+        g = torch.Generator(device=dev).manual_seed(it * 1000 + M + N + K)
+        a = torch.randn((M, K), generator=g, device=dev).to(T); w = (torch.randn((N, K), generator=g, device=dev) / K ** 0.5).to(T)
+        res = torch.randn((M, N), generator=g, device=dev)
+        for od, r in ((T, None), (torch.float32, res)):
+            lib.cor_gemm_set_config(2); ref = ops.gemm(a, w, out_dtype=od, residual=r)
+            lib.cor_gemm_set_config(13); out = ops.gemm(a, w, out_dtype=od, residual=r)
+            if not torch.equal(out, ref):
+                bad += 1; print("GEMM MISMATCH", it, M, N, K, od, float((out.float() - ref.float()).abs().max()), flush=True)
+    lib.cor_gemm_set_config(0)
+    B, H, gsz = 4, 12, 64
+    qkv = torch.randn((B * gsz * gsz, 3 * H * 64), device=dev).to(T); pad = torch.randn((3 * H * 64,), device=dev).to(T)
+    rh = torch.randn((127, 64), device=dev) * 0.5; rw = torch.randn((127, 64), device=dev) * 0.5
+    lib.cor_flash_set_variant(0); o0 = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
+    lib.cor_flash_set_variant(1); o1 = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
+    o1b = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
+    d = float((o0 - o1).abs().max())
+    if d > 0.05 or not torch.equal(o1, o1b) or not bool(torch.isfinite(o1).all()):
+        bad += 1; print("ATTN MISMATCH", it, d, bool(torch.equal(o1, o1b)), flush=True)
+    if it % 5 == 4: print("round", it + 1, "ok so far" if not bad else f"{bad} mismatches", flush=True)
+print("FAILED" if bad else "RACE SCREEN CLEAN", rounds, "rounds")
+sys.exit(1 if bad else 0)
