@@ -304,6 +304,33 @@ def test_sam_attention_vs_reference_golden(tag):
     report(f"sam_attention_golden_{tag}", y.view(3, S, S, dim), g["y"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,amp", [(1, 12, 1.0), (3, 16, 1.0), (2, 12, 6.0), (2, 5, 0.05)])
+def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
+    """flash_global_pipe (software-pipelined, LDS-DMA rings, lazy rescale, MFMA row sums; default) against flash_fwd<1> (one
+    tile at a time, exact running max) on the same inputs: same math, different rounding points (bf16 P is scaled by
+    2^(m_exact - m_lazy) <= 2^8, an exact power of two, so only the row-sum rounding differs). amp = 6 drives score ranges of
+    +-100 (lazy rescale fires often, strong peaks), amp = 0.05 nearly uniform attention."""
+    ops, _ = _ops()
+    from cor_amd import _native as nat
+    lib = nat.load()
+    g = torch.Generator(device=DEV).manual_seed(B * 100 + H)
+    d = H * 64
+    qkv = (torch.randn((B * 4096, 3 * d), generator=g, device=DEV) * amp).to(BF16)
+    pad = torch.randn((3 * d,), generator=g, device=DEV).to(BF16)
+    rh = torch.randn((127, 64), generator=g, device=DEV) * 0.3
+    rw = torch.randn((127, 64), generator=g, device=DEV) * 0.3
+    try:
+        assert lib.cor_flash_set_variant(0) == 0
+        ref = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32)
+        assert lib.cor_flash_set_variant(1) == 0
+        out = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32)
+        out2 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32)
+    finally:
+        lib.cor_flash_set_variant(1)
+    assert torch.equal(out, out2)                                   # run-to-run reproducible
+    report(f"global_attn_pipe_B{B}_H{H}_amp{amp}", out, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("window", [14, 0])
 @pytest.mark.parametrize("T", [F32, BF16])
 def test_sam_attention_real_dims(window, T):
