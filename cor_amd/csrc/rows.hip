@@ -179,6 +179,22 @@ __global__ void __launch_bounds__(256) im2col3x3_kernel(const T* x, T* out, int 
   }
 }
 
+// 16-byte form (row bytes % 16 == 0): one thread per 16-B chunk of one (token, tap); blockIdx.y = image row (b, yh), so the
+// per-thread index math is two small divisions; raw copies, no dtype conversion (the 8-B convert-and-store form ran at 2 TB/s).
+__global__ void __launch_bounds__(256) im2col3x3_raw16_kernel(const uint4* x, uint4* out, int H, int W, int cb) {
+  const int by = blockIdx.y;                                  // b * H + yh
+  const int yh = by % H;
+  const int per_row = W * 9 * cb;                             // chunks of one image row of the output
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per_row; i += gridDim.x * 256) {
+    const int c = i % cb; const int t = i / cb;
+    const int tap = t % 9, xw = t / 9;
+    const int sy = yh + tap / 3 - 1, sx = xw + tap % 3 - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[((long)(by - yh + sy) * W + sx) * cb + c];
+    out[((long)by * W + xw) * 9L * cb + (long)tap * cb + c] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) embed_kernel(const long long* ids, const float* table, const float* pos, float* out,
                                                     int rows, int ctx, int D, int vocab) {
   const long n = (long)rows * (D >> 2);
@@ -287,6 +303,13 @@ extern "C" int cor_patchify(const float* img, void* out, int out_dtype, int B, i
 extern "C" int cor_im2col3x3(const void* x, int dtype, void* out, int B, int H, int W, int C, void* stream) {
   if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return COR_EINVAL;
   const long total = (long)B * H * W * 9 * (C >> 2);
+  const int esz = dtype == COR_F32 ? 4 : 2;
+  if ((dtype == COR_F32 || dtype == COR_BF16) && (C * esz) % 16 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && (long)B * H < 65536) {
+    const int cb = C * esz / 16, per_row = W * 9 * cb;
+    hipLaunchKernelGGL(im2col3x3_raw16_kernel, dim3(cdiv(per_row, 256), B * H), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)out, H, W, cb);
+    COR_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == COR_F32) hipLaunchKernelGGL((im2col3x3_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, H, W, C);
   else if (dtype == COR_BF16) hipLaunchKernelGGL((im2col3x3_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, B, H, W, C);
   else return COR_ENOSUPPORT;

@@ -243,6 +243,12 @@ def test_im2col3x3():
     cols = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), 3, padding=1)           # [B, C*9, HW], k = c*9 + tap
     ref = cols.reshape(2, 16, 9, 64).permute(0, 3, 2, 1).reshape(128, 144)           # -> [B*HW, tap*C + c]
     report("im2col3x3", ops.im2col3x3(x.to(DEV), 2, 8, 8), ref, 0, 0)
+    # 16-byte raw-copy form (bf16, C = 256: the neck's 3x3 conv) and the element form (C = 4: row bytes not a multiple of 16)
+    for (B, H, W, C, T) in ((3, 13, 9, 256, BF16), (2, 7, 5, 4, F32), (1, 64, 64, 256, BF16)):
+        x = torch.from_numpy(rng.standard_normal((B, H, W, C), dtype=np.float32)).to(T)
+        cols = torch.nn.functional.unfold(x.float().permute(0, 3, 1, 2), 3, padding=1)
+        ref = cols.reshape(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C).to(T)
+        report(f"im2col3x3_{B}x{H}x{W}x{C}_{T}", ops.im2col3x3(x.to(DEV), B, H, W), ref, 0, 0)
 
 
 # ======================================================================================================
