@@ -78,6 +78,31 @@ __global__ void __launch_bounds__(256) dwconv7_kernel(const float* x, const floa
   }
 }
 
+// four channels per thread (16-B loads of x and w): the scalar form issued 98 4-byte loads per output and ran at the L1 rate
+template <typename TO>
+__global__ void __launch_bounds__(256) dwconv7_vec4_kernel(const float* x, const float* w_t, const float* bias, TO* out, int B, int H, int W, int C) {
+  const int c4n = C >> 2;
+  const long total = (long)B * H * W * c4n;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4; long t = i / c4n;
+    const int xx = (int)(t % W); t /= W; const int y = (int)(t % H); const int b = (int)(t / H);
+    f32x4 acc = *(const f32x4*)(bias + c);
+    for (int ky = 0; ky < 7; ++ky) {
+      const int sy = y + ky - 3;
+      if (sy < 0 || sy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int sx = xx + kx - 3;
+        if (sx < 0 || sx >= W) continue;
+        const f32x4 xv = *(const f32x4*)(x + (((long)b * H + sy) * W + sx) * C + c), wv = *(const f32x4*)(w_t + (ky * 7 + kx) * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[e], wv[e], acc[e]);       // same order per channel as the scalar form
+      }
+    }
+    st4<TO>(out + (((long)b * H + y) * W + xx) * C + c, acc);
+  }
+}
+
 // ---------------------------------------------------------------- mask-adapter pooling
 // grid (ceil(D/256), B); every block recomputes the P x M softmax weights (P*M <= 8K values) in LDS.
 __global__ void __launch_bounds__(256) adapter_pool_kernel(const float* maps, const float* feat, float* out, int P, int M, int D) {
@@ -306,6 +331,14 @@ extern "C" int cor_conv3x3s2_small(const float* x, int x_channels_last, const fl
 
 extern "C" int cor_dwconv7x7(const float* x, const float* w_t, const float* bias, void* out, int out_dtype, int B, int H, int W, int C, void* stream) {
   if (!x || !w_t || !bias || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return COR_EINVAL;
+  if ((C & 3) == 0 && (((uintptr_t)x | (uintptr_t)w_t | (uintptr_t)bias | (uintptr_t)out) & 15) == 0) {
+    const dim3 g4(grid_for((long)B * H * W * (C >> 2)));
+    if (out_dtype == COR_F32) hipLaunchKernelGGL((dwconv7_vec4_kernel<float>), g4, dim3(256), 0, (hipStream_t)stream, x, w_t, bias, (float*)out, B, H, W, C);
+    else if (out_dtype == COR_BF16) hipLaunchKernelGGL((dwconv7_vec4_kernel<bf16_t>), g4, dim3(256), 0, (hipStream_t)stream, x, w_t, bias, (bf16_t*)out, B, H, W, C);
+    else return COR_ENOSUPPORT;
+    COR_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(grid_for((long)B * H * W * C));
   if (out_dtype == COR_F32) hipLaunchKernelGGL((dwconv7_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x, w_t, bias, (float*)out, B, H, W, C);
   else if (out_dtype == COR_BF16) hipLaunchKernelGGL((dwconv7_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, w_t, bias, (bf16_t*)out, B, H, W, C);

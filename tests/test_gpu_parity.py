@@ -236,6 +236,22 @@ def test_patchify(p, size, T):
     report(f"patchify_p{p}_{T}", ops.patchify(img.to(DEV), p, Kp, T), ref, 0, 0)
 
 
+@pytest.mark.parametrize("C", [8, 6, 96])
+def test_dwconv7x7(C):
+    """Depthwise 7x7, pad 3, channels-last (mask_adapter.py:197-199 ConvNeXt block): the 4-channel vector path (C % 4 == 0) and
+    the scalar path against torch's grouped conv."""
+    ops, _ = _ops()
+    rng = np.random.default_rng(C)
+    B, H, W = 2, 9, 11
+    x = torch.from_numpy(rng.standard_normal((B, H, W, C), dtype=np.float32))
+    w = torch.from_numpy(rng.standard_normal((C, 1, 7, 7), dtype=np.float32) * 0.2)
+    b = torch.from_numpy(rng.standard_normal(C, dtype=np.float32))
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=3, groups=C).permute(0, 2, 3, 1)
+    w_t = w.reshape(C, 49).t().contiguous()                                       # [49, C]
+    out = ops.dwconv7x7(x.to(DEV).reshape(-1, C), w_t.to(DEV), b.to(DEV), B, H, W)
+    report(f"dwconv7x7_C{C}", out.view(B, H, W, C), ref, 1e-5, 1e-5)
+
+
 def test_im2col3x3():
     ops, _ = _ops()
     rng = np.random.default_rng(9)
