@@ -236,6 +236,22 @@ def test_patchify(p, size, T):
     report(f"patchify_p{p}_{T}", ops.patchify(img.to(DEV), p, Kp, T), ref, 0, 0)
 
 
+@pytest.mark.parametrize("C,T", [(64, BF16), (64, F32), (48, F32)])
+def test_upscale_shuffle(C, T):
+    """ConvTranspose2d(k=2,s=2) pixel shuffle of the GEMM output + bias + LayerNorm2d + GELU (mask_decoder.py:54-60): the C = 64
+    four-pixels-per-wave kernel and the generic one against torch."""
+    ops, _ = _ops()
+    rng = np.random.default_rng(C)
+    B, H, W = 2, 5, 7
+    y = torch.from_numpy(rng.standard_normal((B * H * W, 4 * C), dtype=np.float32)).to(T)
+    bias = torch.from_numpy(rng.standard_normal(C, dtype=np.float32))
+    lw = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)); lb = torch.from_numpy(rng.standard_normal(C, dtype=np.float32))
+    t = y.float().view(B, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C) + bias     # [b, 2y+dy, 2x+dx, c]
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(t, (C,), lw, lb, 1e-6)).reshape(-1, C)
+    out = ops.upscale_shuffle(y.to(DEV), B, H, W, C, bias=bias.to(DEV), ln_w=lw.to(DEV), ln_b=lb.to(DEV), eps=1e-6, act=1, out_dtype=F32)
+    report(f"upscale_shuffle_C{C}_{T}", out, ref, 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("C", [8, 6, 96])
 def test_dwconv7x7(C):
     """Depthwise 7x7, pad 3, channels-last (mask_adapter.py:197-199 ConvNeXt block): the 4-channel vector path (C % 4 == 0) and
