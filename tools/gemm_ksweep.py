@@ -8,7 +8,7 @@ from cor_amd import ops, _native
 lib = _native.load(); dev = "cuda:0"; T = torch.bfloat16
 cfgs = [int(c) for c in sys.argv[1:]] or [2, 3]   # 7xx = persistent kernel with ablation knob xx (1 no stores, 2 no epilogue, 4 no MFMA)
 M, N = 131072, 768
-for mode in ("bf16_out", "f32_out_res"):
+for mode in ("bf16_out", "bf16_out_gelu", "f32_out_res"):
     for K in (64, 768, 3072):
         A = torch.randn((M, K), device=dev).to(T); W = (torch.randn((N, K), device=dev) / K ** 0.5).to(T)
         bias = torch.randn((N,), device=dev); R = torch.randn((M, N), device=dev) if mode == "f32_out_res" else None
