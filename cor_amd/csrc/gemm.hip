@@ -764,7 +764,8 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     cfg = (k128 && M >= 512 && N >= 64) ? ((N <= 256 && K >= 2048 && M >= 65536) ? 9 : COR_GEMM_DEFAULT_BIG) : 1;
     // persistent 256x256 ping-pong kernel once its tiles cover most CUs (tools/gemm_bench.py, profiles/r01_gemm_pingpong.txt:
     // +9..45 % from 216 tiles up, -12 % at 72-128 tiles)
-    if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 200) cfg = 13;
+    // (and N fills at least 3/4 of its 256-wide tiles: at N = 128 the half-empty tile loses 10 % to the 128x128 kernel)
+    if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 200 && 4L * N >= 3L * 256 * cdiv(N, 256)) cfg = 13;
   }
   if (!k128 && cfg == 2) cfg = 1;
   if (cfg == 13 || cfg == 14) {
