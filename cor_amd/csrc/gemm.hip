@@ -764,10 +764,12 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     cfg = (k128 && M >= 512 && N >= 64) ? ((N <= 256 && K >= 2048 && M >= 65536) ? 9 : COR_GEMM_DEFAULT_BIG) : 1;
     // persistent 256x256 ping-pong kernel once its tiles cover most CUs (tools/gemm_bench.py, profiles/r01_gemm_pingpong.txt:
     // +9..45 % from 216 tiles up, -12 % at 72-128 tiles)
+    // small GEMMs (text tower, 2048 rows): 64x64 tiles put 4x the blocks on the 256 CUs (+16..25 % at N = 768, nothing at N >= 2304)
+    if (cfg == 2 && (long)cdiv(M, 128) * cdiv(N, 128) < 128) cfg = 4;
     // (and N fills at least 3/4 of its 256-wide tiles: at N = 128 the half-empty tile loses 10 % to the 128x128 kernel)
     if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 200 && 4L * N >= 3L * 256 * cdiv(N, 256)) cfg = 13;
   }
-  if (!k128 && cfg == 2) cfg = 1;
+  if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
   if (cfg == 13 || cfg == 14) {
     const long c_bytes = (((long)M - 1) * ldc + N) * (long)sizeof(TO);
     const bool ok = sizeof(TA) == 2 && k128 && g.vec_epi && !col_scale && N % 8 == 0 && c_bytes < (1L << 32) - 64 &&
@@ -798,6 +800,8 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   switch (cfg) {
     case 9: return launch_tile<TA, TO, 256, 128, 4, 2, true, 3>(g, s);
     case 2: return launch_tile<TA, TO, 128, 128, 2, 2, true>(g, s);
+    case 3: return launch_tile<TA, TO, 128, 64, 2, 2, true>(g, s);      // small-M GEMMs: more, smaller tiles to fill 256 CUs
+    case 4: return launch_tile<TA, TO, 64, 64, 2, 2, true>(g, s);
     default: return launch_tile<TA, TO, 128, 128, 2, 2, false>(g, s);
   }
 }

@@ -23,6 +23,10 @@ SHAPES = [  # (M, N, K, act, residual, out_f32, label)
     (131072, 256, 768, 0, False, True, "neck 1x1"),
     (2048, 2304, 768, 0, False, False, "text qkv"),
     (8192, 1024, 1024, 0, True, True, "M=8192 square"),
+    (2048, 3072, 768, 1, False, False, "text fc1+gelu"),
+    (2048, 768, 3072, 0, True, True, "text fc2+res"),
+    (2048, 768, 768, 0, True, True, "text proj+res"),
+    (18432, 1024, 256, 1, False, False, "adapter 18432x1024x256"),
     (131072, 128, 256, 0, False, False, "decoder k/v proj N=128"),
     (131072, 256, 128, 0, True, True, "decoder out proj K=128"),
     (131072, 256, 256, 0, False, False, "decoder 256x256"),
