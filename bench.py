@@ -45,7 +45,7 @@ def parse():
 
 
 def cpu_baseline(args):
-    """The CPU oracle (fp32 PyTorch-CPU restatement of the reference, pinned by tests/golden) on ONE triplet of the
+    """The CPU oracle (fp32 PyTorch-CPU restatement of the reference, pinned by tests/golden) on THREE triplets of the
     same workload + similarity vs the same gallery size. kind = "port"."""
     from oracle import config as ocfg, model as omodel, retrieval as oret
     from tests.golden_util import make_inputs
@@ -53,15 +53,16 @@ def cpu_baseline(args):
     torch.set_num_threads(ncores)
     spec = ocfg.model_spec(args.sam, args.siglip, "MaskAdapterPooling")
     sd = ocfg.random_state(spec, seed=0)
-    inp = make_inputs(1, q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 32000), mask=("mask", 1, 384))
+    NB = 3                                              # bounded sample: 3 triplets ~ 14 s on 16 cores (the contract asks for 10-30 s)
+    inp = make_inputs(1, q=(NB, 3, 1024, 1024), s=(NB, 3, 384, 384), text=("tokens", NB, 64, 32000), mask=("mask", NB, 384))
     G = torch.nn.functional.normalize(torch.randn(args.gallery or 10000, 256), dim=-1)
     t0 = time.perf_counter()
     with torch.no_grad():
         masks, emb, feat = omodel.forward(sd, args.sam, args.siglip, "MaskAdapterPooling", inp["q"], inp["s"], inp["text"], inp["mask"], True)
         oret.similarity_topk(feat[:, 0], G, args.topk)
     dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 triplet (SAM-B+SigLIP-B/16 fp32 forward + {G.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s")
+    return dict(value=NB / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{NB} triplets in one batch (SAM-B+SigLIP-B/16 fp32 forward + {G.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s")
 
 
 def main():
