@@ -250,17 +250,20 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
     if (more) FA_GLOAD(t + 1)
     const char* Ks = smem + (t & 1) * 2 * TILE_B; const char* Vs = Ks + TILE_B;
 
-    // S^T = K . Q^T
+    // S^T = K . Q^T. All eight K fragments are read before the MFMAs (a read placed right before its MFMA exposes the LDS latency
+    // once per MFMA; see flash_global_pipe).
     f32x16 s[2];
+    uint4 kfr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kfr[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint4 kf = *(const uint4*)(Ks + kb * 32 * 128 + kch[c]);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
-      }
+      for (int c = 0; c < 4; ++c)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
     }
     // logits in the log2 domain. MODE 1: the per-tile row term rh is the same for all 64 keys of the tile, so it is
     // folded into the running-max bookkeeping instead of being added to 32 registers. MODE 2: the tile holds key rows
@@ -325,25 +328,25 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
-    // O^T += V^T . P^T
+    // O^T += V^T . P^T (all eight transposed V fragments first), row sums of P on the matrix pipe: ones . P^T leaves
+    // sum_k P[k][q] (over the bf16-rounded P, as the numerator) in every row of lsum - 32 VALU adds per tile saved
+    uint4 vfr[8];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int i = 0; i < 8; ++i) {
+      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
+      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + db * 64 + v_tr;
+      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
+      const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+      vfr[i] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int krow = kb * 32 + ks * 16;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const char* vb = Vs + krow * 128 + db * 64 + v_tr;
-          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
-          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
-          const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
-          const uint4 vf = make_uint4(u0.x, u0.y, u1.x, u1.y);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-        }
-        // row sums of P on the matrix pipe: ones . P^T leaves sum_k P[k][q] (over the bf16-rounded P, as the numerator) in every
-        // row of lsum - 32 VALU adds per tile saved
-        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
+      if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
+    }
     if (more) FA_LSTORE((t + 1) & 1)
     __syncthreads();
   };
