@@ -68,6 +68,49 @@ __device__ __forceinline__ uint4 table_frag(const float* tbl, int j, int c, int 
   return pack8(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
 }
 
+// Output store. O^T leaves a query on each lane (32 queries x 64 values per wave): storing it from there is 8 x 8-byte stores
+// per lane that touch 32 different output rows per instruction (16-B pieces) - a store-ISSUE-bound tail (MI355X guide: ~9k
+// cycles; 61 % of a windowed block's lifetime was prologue + this tail). Instead the wave transposes its tile through 4.6 KB of
+// its own LDS (row stride 144 B: conflict-free for both passes) and each instruction stores 8 whole 128-byte rows.
+// off(j) = element offset of local query j's output row, or -1 when that query does not exist.
+template <typename TO, typename OFF>
+__device__ __forceinline__ void store_o_rows(const f32x16 (&o)[2], float inv, char* stg, TO* out, int lane, OFF&& off) {
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 u;
+        u.x = pk2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv); u.y = pk2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        *(uint2*)(stg + r * 144 + (db * 32 + 8 * g + 4 * h) * 2) = u;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = (lane >> 3) + 8 * i, ch = lane & 7;
+      const uint4 v = *(const uint4*)(stg + j * 144 + ch * 16);
+      const long e = off(j);
+      if (e >= 0) *(uint4*)(out + e + ch * 8) = v;
+    }
+  } else {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {                   // fp32 rows are 256 B: one 128-B half per pass
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v4 = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+        *(f32x4*)(stg + r * 144 + (8 * g + 4 * h) * 4) = v4;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = (lane >> 3) + 8 * i, ch = lane & 7;
+        const f32x4 v = *(const f32x4*)(stg + j * 144 + ch * 16);
+        const long e = off(j);
+        if (e >= 0) *(f32x4*)(out + e + db * 32 + ch * 4) = v;
+      }
+    }
+  }
+}
+
 template <int MODE, typename TO>
 __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -356,16 +399,18 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < nt) tile(nt - 1, std::true_type{});
 
-  if (!qvalid) return;
   const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
-  TO* op = MODE == 0 ? (TO*)a.o + bz * a.o_sb + (long)tq * a.o_st + head * 64 : (TO*)a.o + orow * (long)(a.H * 64) + head * 64;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v4 = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
-      st4<TO>(op + db * 32 + 8 * g + 4 * h, v4);
-    }
+  // staging: the K/V buffers (every wave is past the last tile's barrier), 8 KiB per wave
+  auto off = [&](int j) -> long {
+    const int tj = qt_ * 128 + wave * 32 + j;
+    if (tj >= a.Tq) return -1;
+    if (MODE == 0) return bz * a.o_sb + (long)tj * a.o_st + head * 64;
+    if (MODE == 1) return ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64;
+    const int y = wy * S + tj / S, x = wx * S + (tj - (tj / S) * S);
+    if (y >= a.grid || x >= a.grid) return -1;
+    return ((long)b * g2 + (long)y * a.grid + x) * (long)(a.H * 64) + head * 64;
+  };
+  store_o_rows<TO>(o, inv, smem + wave * 8192, (TO*)a.o, lane, off);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -622,16 +667,12 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       }
   }
 
-  if (!qvalid) return;
   const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
-  TO* op = (TO*)a.o + orow * (long)(a.H * 64) + head * 64;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v4 = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
-      st4<TO>(op + db * 32 + 8 * g + 4 * h, v4);
-    }
+  auto off = [&](int j) -> long {
+    const int tj = qt_ * 128 + wave * 32 + j;
+    return tj < a.Tq ? ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64 : -1L;
+  };
+  store_o_rows<TO>(o, inv, (char*)aux, (TO*)a.o, lane, off);       // the wave's row-bias table is dead: 8 KiB of private staging
 }
 
 template <typename TO>
@@ -673,8 +714,8 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
   if ((q_st | k_st | v_st | q_sb | k_sb | v_sb) & 7) return COR_ENOSUPPORT;
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return COR_ENOSUPPORT;
-  if ((o_st | o_sb) & 3) return COR_ENOSUPPORT;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return COR_ENOSUPPORT;
+  if ((o_st | o_sb) & 7) return COR_ENOSUPPORT;         // 16-byte row stores
   FlashArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = out;
   a.q_sb = q_sb; a.q_st = q_st; a.k_sb = k_sb; a.k_st = k_st; a.v_sb = v_sb; a.v_st = v_st; a.o_sb = o_sb; a.o_st = o_st;
@@ -686,7 +727,7 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
 
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w, int B,
                        int H, int grid, int window, hipStream_t s) {
-  if (((uintptr_t)qkv & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
   a.q = (const bf16_t*)qkv; a.o = out; a.H = H; a.scale_log2 = 0.125f * LOG2E;
   a.pad_row = (const bf16_t*)pad_row; a.rel_h = rel_h; a.rel_w = rel_w; a.grid = grid; a.d3 = 3 * H * 64;
