@@ -4,12 +4,14 @@
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): SAM-ViT-B + SigLIP-B/16-384 + MaskAdapterPooling, batch 32 triplets per GPU,
-bf16 fast mode, synthetic inputs / random-init weights, 10k-row bf16 gallery (N=1). For N>1 (configs[2]) a 100k-row
-gallery is row-sharded over the ranks, queries are all-gathered over RCCL, each rank scores all queries against its
-shard, per-shard top-k lists are merged on the host. A "step" = one such pass; inputs are resident in HBM.
+Workload (BASELINE.json metric: "query triplets/sec + Recall@1 vs 100k-region gallery"; model/batch of configs[1]):
+SAM-ViT-B + SigLIP-B/16-384 + MaskAdapterPooling, batch 32 triplets per GPU, bf16 fast mode, synthetic inputs /
+random-init weights, 100k-row bf16 gallery at every N (51 MB: fits one GPU). For N>1 (configs[2]) the gallery is
+row-sharded over the ranks, queries are all-gathered over RCCL, each rank scores all queries against its shard, the packed
+per-shard top-k lists go to rank 0 in one gather and are merged on the host. A "step" = one such pass; inputs resident in HBM.
 One JSON line on rank 0. `roofline` is for the dominant kernel (the bf16 MFMA GEMM); `cpu_baseline` is the CPU oracle
-timed on the host cores on a bounded sample (1 triplet) at N=1.
+timed on the host cores on a bounded sample (3 triplets) at N=1; `recall_at_1` (outside the timed region) compares the
+bf16 HIP pipeline's top-1 with the fp32 CPU oracle's on those triplets against the same gallery with planted positives.
 """
 from __future__ import annotations
 
@@ -31,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
-    ap.add_argument("--gallery", type=int, default=0, help="total gallery rows (default 10k at N=1, 100k at N>1)")
+    ap.add_argument("--gallery", type=int, default=100000, help="total gallery rows (BASELINE metric: 100k-region gallery)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--sam", default="sam_base")
     ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
@@ -44,25 +46,58 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """The CPU oracle (fp32 PyTorch-CPU restatement of the reference, pinned by tests/golden) on THREE triplets of the
-    same workload + similarity vs the same gallery size. kind = "port"."""
-    from oracle import config as ocfg, model as omodel, retrieval as oret
-    from tests.golden_util import make_inputs
+NB_CPU = 3          # bounded CPU sample: 3 triplets ~ 14 s on 16 cores (the contract asks for 10-30 s)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # written by tools/pmc_traffic.py for THIS build
+
+
+def gemm_source_id():
+    """sha256 over the GEMM kernel sources: a PMC traffic file is only quoted for the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "cor_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev):
+    """(1) cpu_baseline: the CPU oracle (fp32 PyTorch-CPU restatement of the reference, pinned by tests/golden; kind "port")
+    on the first NB_CPU triplets of the SAME synthetic batch with the SAME weights + similarity vs the same gallery.
+    (2) recall_at_1: positives are planted for those triplets from the oracle's fp32 query features
+    (gallery[pi(b)] = normalize(q_b + 0.1 N(0,1))); the bf16 HIP pipeline (forward + cor_similarity_topk on the bf16 gallery)
+    must return the same top-1 as the fp32 CPU oracle (fp32 features, fp32 product on the same stored rows)."""
+    from oracle import model as omodel, retrieval as oret
+    from cor_amd import retrieval
     ncores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives one GPU's share of the host: 16 cores
     torch.set_num_threads(ncores)
-    spec = ocfg.model_spec(args.sam, args.siglip, "MaskAdapterPooling")
-    sd = ocfg.random_state(spec, seed=0)
-    NB = 3                                              # bounded sample: 3 triplets ~ 14 s on 16 cores (the contract asks for 10-30 s)
-    inp = make_inputs(1, q=(NB, 3, 1024, 1024), s=(NB, 3, 384, 384), text=("tokens", NB, 64, 32000), mask=("mask", NB, 384))
-    G = torch.nn.functional.normalize(torch.randn(args.gallery or 10000, 256), dim=-1)
+    sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    inp = {k: v[:NB_CPU].cpu() for k, v in batch.items()}
+    G32 = gallery_rows_cpu.to(torch.bfloat16).float()   # the stored (bf16) rows, as the oracle sees them
     t0 = time.perf_counter()
     with torch.no_grad():
-        masks, emb, feat = omodel.forward(sd, args.sam, args.siglip, "MaskAdapterPooling", inp["q"], inp["s"], inp["text"], inp["mask"], True)
-        oret.similarity_topk(feat[:, 0], G, args.topk)
+        _, _, feat = omodel.forward(sd, args.sam, args.siglip, "MaskAdapterPooling", inp["query_image_inputs"], inp["support_image_inputs"],
+                                    inp["change_text_inputs"], inp["support_mask_inputs"], True)
+        oret.similarity_topk(feat[:, 0], G32, args.topk)
     dt = time.perf_counter() - t0
-    return dict(value=NB / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{NB} triplets in one batch (SAM-B+SigLIP-B/16 fp32 forward + {G.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s")
+    cpu = dict(value=NB_CPU / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"{NB_CPU} triplets in one batch ({args.sam}+{args.siglip} fp32 forward + {G32.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s")
+    # ---- recall (outside every timed region)
+    q_ref = feat[:, 0].float()
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    where = torch.arange(NB_CPU) * 7919 + 13
+    G = gallery_rows_cpu.clone()
+    G[where] = torch.nn.functional.normalize(q_ref + 0.1 * torch.randn(q_ref.shape, generator=gen), dim=-1)
+    G = G.to(torch.bfloat16)
+    rs, ri = oret.similarity_topk(q_ref, G.float(), args.topk)                       # fp32 CPU oracle end to end
+    with torch.no_grad():
+        _, _, f_gpu = model(**{k: v[:NB_CPU] for k, v in batch.items()}, multimask_output=True)
+    gs, gi = retrieval.GalleryShard(G.to(dev), 0).search(f_gpu[:, 0], args.topk)
+    gi = gi.cpu()
+    rec = dict(recall_at_1=float((gi[:, 0] == ri[:, 0]).float().mean()), queries=NB_CPU,
+               recall_at_1_planted=float((gi[:, 0] == where).float().mean()), oracle_recall_at_1_planted=float((ri[:, 0] == where).float().mean()),
+               topk_index_mismatches=int((gi != ri).sum()), topk_entries=int(ri.numel()),
+               feature_max_abs_err=float((f_gpu[:, 0].cpu() - q_ref).abs().max()),
+               definition="top-1 of the bf16 HIP pipeline == top-1 of the fp32 CPU oracle (same weights, inputs, gallery with planted positives)")
+    return cpu, rec
 
 
 def main():
@@ -95,18 +130,18 @@ def main():
     model.compute_dtype = T
     B = args.batch
     batch = utils.synthetic_batch(B, dev, seed=rank)
-    Gtot = args.gallery or (10000 if world == 1 else 100000)
+    Gtot = args.gallery
     lo, hi = retrieval.shard_bounds(Gtot, world, rank)
     gen = torch.Generator(device="cpu").manual_seed(1234)
-    rows = torch.nn.functional.normalize(torch.randn((Gtot, 256), generator=gen), dim=-1)[lo:hi]
-    shard = retrieval.GalleryShard(rows.to(dev), offset=lo, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    rows_all = torch.nn.functional.normalize(torch.randn((Gtot, 256), generator=gen), dim=-1)
+    shard = retrieval.GalleryShard(rows_all[lo:hi].to(dev), offset=lo, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
 
     host_batch = {k: v.cpu().pin_memory() for k, v in batch.items()} if args.host_inputs else None
 
     def step():
         b = {k: v.to(dev, non_blocking=True) for k, v in host_batch.items()} if host_batch is not None else batch
         masks, emb, feat = model(**b, multimask_output=True)
-        return retrieval.distributed_search(feat[:, 0], shard, args.topk)
+        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B)    # results on rank 0 (merged once)
 
     def barrier():
         if world > 1:
@@ -135,14 +170,16 @@ def main():
     n_launch = sum(1 for p in prof if p[3] == T)
     # HBM traffic of that kernel cannot be read live: it comes from the committed rocprofv3 --pmc passes of THIS command
     # (tools/pmc_traffic.py -> profiles/*pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction), per launch.
-    traffic = None
-    import glob
-    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if tf and args.dtype == "bf16" and world == 1 and B == 32:
+    traffic, traffic_note = None, "no PMC pass for this build"
+    if os.path.exists(PMC_TRAFFIC_FILE) and args.dtype == "bf16" and world == 1 and B == 32 and args.sam == "sam_base":
         try:
-            traffic = json.load(open(tf[-1]))["bytes_per_launch"]
-        except Exception:
-            traffic = None
+            tj = json.load(open(PMC_TRAFFIC_FILE))
+            if tj.get("gemm_source_id") == gemm_source_id():
+                traffic, traffic_note = tj["bytes_per_launch"], f"{os.path.relpath(PMC_TRAFFIC_FILE, ROOT)} (same GEMM sources: {tj['gemm_source_id']})"
+            else:
+                traffic_note = f"{os.path.relpath(PMC_TRAFFIC_FILE, ROOT)} was measured on other GEMM sources ({tj.get('gemm_source_id')}): not quoted"
+        except Exception as e:                           # noqa: BLE001
+            traffic_note = f"unreadable PMC file: {e}"
     peak = 2500.0 if T == torch.bfloat16 else 157.3
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
 
@@ -155,12 +192,14 @@ def main():
                                    + (f" sharded {world} ways (RCCL all-gather of queries, host top-k merge)" if world > 1 else ""),
                        "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
             "roofline": {"bound": "mfma", "kernel": ("cor_gemm, bf16 operands: gemm_pp<*> (persistent 256x256 ping-pong, >= 200 tiles) + gemm_tile<bf16,*,128,128> (the rest)" if args.dtype == "bf16" else "cor_gemm, fp32 operands: gemm_tile<float,float,128,128> on v_mfma_f32_32x32x2_f32"), "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, offline pass)",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, offline pass)", "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": gemm_bytes / max(n_launch, 1), "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args)
+            res["cpu_baseline"], rec = cpu_baseline_and_recall(args, model, batch, rows_all, dev)
+            res["recall_at_1"] = rec["recall_at_1"]
+            res["recall"] = rec
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

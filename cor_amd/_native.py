@@ -14,18 +14,17 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcor_amd.so")
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4
 EINVAL, ENOSUPPORT = -1, -2
+TOPK_FORCE_LISTS, TOPK_NO_FALLBACK = 1, 2
 
 _p, _i, _l, _f, _ll = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_longlong
 
 # name -> argtypes (restype int unless noted); order follows include/cor_amd.h exactly
 SIGNATURES = {
     "cor_version": [],
-    "cor_gemm": [_p, _l, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _i, _p, _p, _l, _i, _p],
-    "cor_gemm_set_config": [_i],
+    "cor_gemm": [_p, _l, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _i, _p, _p, _l, _i, _i, _p],
     "cor_layernorm": [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p],
     "cor_attention": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p, _l, _l, _i, _i, _i, _i, _i, _i, _f, _p],
-    "cor_sam_attention": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "cor_flash_set_variant": [_i],
+    "cor_sam_attention": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cor_patchify": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cor_im2col3x3": [_p, _i, _p, _i, _i, _i, _i, _p],
     "cor_add": [_p, _i, _p, _i, _p, _i, _l, _l, _p],
@@ -50,9 +49,8 @@ SIGNATURES = {
     "cor_resample_rows_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "cor_resample_cols_u8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "cor_mask_metrics": [_p, _p, _p, _i, _i, _f, _p],
-    "cor_topk_set_mode": [_i],
     "cor_topk_workspace_bytes": [_i, _i, _i],
-    "cor_similarity_topk": [_p, _p, _i, _i, _i, _i, _i, _ll, _p, _p, _p, _p],
+    "cor_similarity_topk": [_p, _p, _i, _i, _i, _i, _i, _ll, _p, _p, _p, _i, _p],
 }
 _RESTYPE = {"cor_topk_workspace_bytes": _l}
 

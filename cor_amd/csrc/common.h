@@ -114,3 +114,31 @@ __device__ __forceinline__ void glds16_so(const void* sbase, unsigned voff, unsi
 }
 
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- per-DEVICE one-time host state -----------------------------------------------------------------------------------
+// The > 64 KiB dynamic-LDS attribute of a kernel and the CU count belong to a device, not to the process: a second GPU in
+// the same process (model on cuda:1) must get its own hipFuncSetAttribute. Everything is keyed by the CURRENT device id;
+// the Python front end guarantees the operands live on that device (cor_amd/ops.py:_dev).
+constexpr int COR_MAX_DEVICES = 64;
+static inline int cor_cur_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < COR_MAX_DEVICES) ? d : 0;
+}
+struct DevOnce { bool done[COR_MAX_DEVICES] = {}; };
+static inline void cor_max_dyn_lds(const void* fn, int bytes, DevOnce& once) {
+  const int d = cor_cur_device();
+  if (!once.done[d]) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    once.done[d] = true;
+  }
+}
+static inline int cor_device_cus() {
+  static int n[COR_MAX_DEVICES] = {};
+  const int d = cor_cur_device();
+  if (n[d] == 0) {
+    hipDeviceProp_t prop;
+    n[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n[d];
+}

@@ -678,11 +678,8 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 template <typename TO>
 int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)flash_global_pipe<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, 128);
   hipLaunchKernelGGL((flash_global_pipe<TO>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
@@ -693,11 +690,8 @@ int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
 template <int MODE, typename TO>
 int launch(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = KV_BYTES + (MODE == 0 ? 0 : 4 * AUX_PER_WAVE);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)flash_fwd<MODE, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)flash_fwd<MODE, TO>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, 128);
   hipLaunchKernelGGL((flash_fwd<MODE, TO>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
@@ -707,9 +701,8 @@ int launch(const FlashArgs& a, int nb, hipStream_t s) {
 
 }  // namespace
 
-int g_flash_global_variant = 1;      // 1 (default): flash_global_pipe, software-pipelined over key tiles (2.38 ms at B=32); 0: flash_fwd<1> (2.67 ms)
-extern "C" int cor_flash_set_variant(int v) { g_flash_global_variant = v ? 1 : 0; return 0; }
-
+// `variant` (per call): 0 (default) = flash_global_pipe, software-pipelined over key tiles; 1 = flash_fwd<1>, the unpipelined
+// chain form (kept as the in-process A/B and parity partner: tests/test_gpu_parity.py, tools/attn_bench.py).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -726,7 +719,7 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
 }
 
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w, int B,
-                       int H, int grid, int window, hipStream_t s) {
+                       int H, int grid, int window, int variant, hipStream_t s) {
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
   a.q = (const bf16_t*)qkv; a.o = out; a.H = H; a.scale_log2 = 0.125f * LOG2E;
@@ -734,7 +727,7 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   if (window == 0) {
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
-    if (g_flash_global_variant == 1) {
+    if (variant == 0) {
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, s);
     }

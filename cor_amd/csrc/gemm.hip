@@ -12,8 +12,11 @@
 //             (k order inside a step is permuted identically for A and W, which a dot product does not see);
 //   * LDS rows are 128 B, so chunk c of row r is stored at chunk slot c ^ ((r>>1)&7): the 16 rows of one
 //     ds_read_b128 lane group then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free);
-//   * register-staged double buffering (global_load_dwordx4 for tile t+1 issued before the MFMAs of tile t,
-//     written to the other LDS buffer after them), one barrier per K-step;
+//   * operands go global -> LDS directly (global_load_lds_dwordx4 from inline asm, lane-linear LDS image, swizzle on the
+//     per-lane SOURCE chunk; GLDS = true), double buffered, one barrier per K-step; the register-staged form
+//     (global_load_dwordx4 for tile t+1 issued before the MFMAs of tile t, ds_write after them; GLDS = false) remains for
+//     K tails that direct-to-LDS staging cannot zero-fill and for unaligned operands;
+//   * gemm_pp (further down): persistent 256x256 ping-pong kernel for >= 200 output tiles (see its own header);
 //   * XCD-aware tile order: blocks that share an XCD walk N-tiles of the same A row-panel (L2 reuse of A).
 #include "common.h"
 
@@ -719,17 +722,15 @@ __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, cons
   }
 }
 
-int g_gemm_cfg = 0, g_gemm_dbg = 0;   // 0 = auto; 1, 2, 9, 13, 14 force a kernel (tools/gemm_bench.py); other values behave as 1
+// `cfg` (per call, last argument of cor_gemm): low byte 0 = auto; 1, 2, 3, 4, 9, 13, 14 force a kernel (tools/gemm_bench.py);
+// bits 8.. = timing-only ablation / tile-order knobs of the persistent kernel (tools/gemm_ksweep.py). No process-global state.
 
 template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS, int NBUF = 2>
 int launch_tile(GemmArgs g, hipStream_t s) {
   constexpr int LDS = NBUF * (BM + BN) * ROWB;
   g.tm = cdiv(g.M, BM); g.tn = cdiv(g.N, BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tile<TA, TO, BM, BN, WM, WN, GLDS, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)gemm_tile<TA, TO, BM, BN, WM, WN, GLDS, NBUF>, LDS, once);
   hipLaunchKernelGGL((gemm_tile<TA, TO, BM, BN, WM, WN, GLDS, NBUF>), dim3(g.tm * g.tn), dim3(WM * WN * 64), LDS, s, g);
   COR_CHECK_LAUNCH();
   return 0;
@@ -738,7 +739,8 @@ int launch_tile(GemmArgs g, hipStream_t s) {
 template <typename TA, typename TO>
 int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                 const float* bias, int act, const float* col_scale, const float* residual, long ldr, int res_row_mod,
-                hipStream_t s) {
+                int cfg_arg, hipStream_t s) {
+  const int g_gemm_cfg = cfg_arg & 0xff, g_gemm_dbg = cfg_arg >> 8;
   const long esz = sizeof(TA);
   const bool fast = (K * esz) % 16 == 0 && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0 &&
                     ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0);
@@ -777,16 +779,10 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     if (!ok) cfg = k128 ? 2 : 1;
     else if constexpr (sizeof(TA) == 2) {
       g.tm = cdiv(g.M, 256); g.tn = cdiv(g.N, 256);
-      static int n_cu = 0;
-      static bool attr_pp = false;
-      if (!attr_pp) {
-        int dev = 0; hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
-        n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        (void)hipFuncSetAttribute((const void*)gemm_pp<TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_pp<TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        attr_pp = true;
-      }
+      static DevOnce once_a, once_b;
+      const int n_cu = cor_device_cus();
+      cor_max_dyn_lds((const void*)gemm_pp<TO, false>, 163840, once_a);
+      cor_max_dyn_lds((const void*)gemm_pp<TO, true>, 163840, once_b);
       const int total = g.tm * g.tn;
       int blocks = n_cu - (n_cu & 7);
       if (total < blocks) blocks = ((total + 7) / 8) * 8;
@@ -808,26 +804,20 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
 
 }  // namespace
 
-extern "C" int cor_gemm_set_config(int cfg) {
-  if (cfg >= 100) { g_gemm_dbg = cfg - 100; return 0; }            // timing-only ablation knobs (persistent kernel)
-  if (cfg < 0 || cfg > 14) return COR_EINVAL;
-  g_gemm_cfg = cfg;
-  return 0;
-}
-
 extern "C" int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype, void* C, long ldc, int c_dtype,
                         int M, int N, int K, const float* bias, int act, const float* col_scale,
-                        const float* residual, long ldr, int res_row_mod, void* stream) {
+                        const float* residual, long ldr, int res_row_mod, int cfg, void* stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldc < N) return COR_EINVAL;
+  if (cfg < 0 || (cfg & 0xff) > 14) return COR_EINVAL;
   if (residual && ldr < N) return COR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (ab_dtype == COR_F32 && c_dtype == COR_F32)
-    return launch_gemm<float, float>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, s);
+    return launch_gemm<float, float>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, cfg, s);
   if (ab_dtype == COR_BF16 && c_dtype == COR_BF16)
-    return launch_gemm<bf16_t, bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, s);
+    return launch_gemm<bf16_t, bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, cfg, s);
   if (ab_dtype == COR_BF16 && c_dtype == COR_F32)
-    return launch_gemm<bf16_t, float>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, s);
+    return launch_gemm<bf16_t, float>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, cfg, s);
   if (ab_dtype == COR_F32 && c_dtype == COR_BF16)
-    return launch_gemm<float, bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, s);
+    return launch_gemm<float, bf16_t>(A, lda, W, ldw, C, ldc, M, N, K, bias, act, col_scale, residual, ldr, res_row_mod, cfg, s);
   return COR_ENOSUPPORT;
 }

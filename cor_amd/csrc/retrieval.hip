@@ -3,7 +3,10 @@
 //   score[b,g] = Q[b,:] . G[g,:]   (unit vectors: cosine, utils/loss_func.py:84)  ->  per query top-k by
 //   (score desc, global index asc).
 //
-// The [Bq, Ng] score matrix is never written to HBM. One WAVE owns 32 queries (their K-fragments stay in
+// The [Bq, Ng] score matrix is never written to HBM. 16-bit galleries with C = 256 (the CORE embedding width) take the
+// threshold-and-append pipeline further down (sim_scan: MFMA scan + exact fp32-chain re-scoring of the short list =>
+// top-k indices and scores BIT-IDENTICAL to the CPU chain oracle); what follows first are the per-lane sorted-list kernels
+// (fp32 galleries: the exact-chain form; 16-bit: the always-available fallback). One WAVE owns 32 queries (their K-fragments stay in
 // registers for the whole kernel) and streams a slice of gallery rows through the MFMA as the A operand:
 // D[row = gallery row, col = query] puts each query on a lane, so every lane keeps a private sorted top-k list
 // of its own 16 scores per 32x32 tile (compare against the list minimum; insertion is rare after warm-up).
@@ -185,7 +188,8 @@ __device__ __forceinline__ uint4 q_frag16(const float* qrow, int c, int h) {
 
 template <typename TG, int KMAX>
 __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ Q, const TG* __restrict__ G, int Bq, int Ng,
-                                                      TopkPlan2 plan, float* ws_s, int* ws_i) {
+                                                      TopkPlan2 plan, float* ws_s, int* ws_i, const int* gate) {
+  if (gate && *gate == 0) return;                               // device-side fallback: runs only after a candidate overflow
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 16 KiB gallery tiles
   constexpr int C = 256, TILE = 32 * C * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -278,189 +282,239 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// v3 (16-bit galleries, large shards): threshold-and-append. Per-lane sorted lists cost one divergent insertion bubble
-// (~500 wave cycles) per accepted score, and a stream of n scores accepts ~k ln(n/k) of them per lane: measured 9x the
-// MFMA time. Instead:
-//   1. DENSE pass over a strided sample of S gallery rows writes the [Bq, S] scores (same MFMA code, same arithmetic);
-//   2. the k-th best sample score of a query, tau_q, is a valid LOWER bound of its k-th best overall score;
-//   3. APPEND pass over the whole shard: a lane only compares its tile maximum with tau_q and appends the rare
-//      scores >= tau_q (expected k*Ng/S per query) to a per-query candidate list (atomic slot counter);
-//   4. exact selection over the candidates by (score desc, index asc).
-// Every row of the global top-k has score >= tau_q, so the result is exact; a candidate-list overflow (pathological
-// score distributions) is reported through index -2 and the caller re-runs the list kernel.
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 (16-bit galleries, C = 256, every shard size): threshold-and-append with EXACT re-scoring.
+// Per-lane sorted lists cost one divergent insertion bubble (~500 wave cycles) per accepted score, and a stream of n scores
+// accepts ~k ln(n/k) of them per lane: measured 9x the MFMA time. Instead, four launches:
+//   A. sim_scan<SAMPLE>: MFMA scores of a strided SAMPLE of 32-row tiles; every (gallery slice, lane half) group keeps only
+//      its MAXIMUM per query. The groups are disjoint row sets, so the k-th largest group maximum is a LOWER bound of the
+//      query's k-th best score over the whole shard (no dense score matrix, no selection pass).
+//   B. sim_tau: tau_q = that k-th largest group maximum minus delta_q (one wave per query).
+//   C. sim_scan<APPEND>: MFMA scores of the WHOLE shard; a lane compares its tile maximum with tau_q and appends the rare
+//      scores >= tau_q to the private list of its (query, gallery slice, lane half) stream (register counter, no atomics).
+//   D. sim_final: per query, the candidates are compacted into LDS, the k-th best MFMA score T is found by a 4-pass radix
+//      select, the SHORT LIST (MFMA score >= T - delta_q, ~k entries) is RE-SCORED with the exact fp32 fmaf chain of
+//      oracle/c/sim_chain.c over the stored 16-bit values (the query rounded to the gallery dtype), and ranked by
+//      (chain score desc, index asc).
+// Exactness. Let s~ be the MFMA score (fp32 accumulation of exact bf16/fp16 products in the matrix core's order) and s the
+// chain score. Both are fp32 summations of the same 256 exact products, so |s~ - s| <= eps_q := 2^-23 * 255/... bounded by
+// 2 * 255 * 2^-24 * sum|q_k g_k| <= 3.1e-5 * |q| |g| (one rounding per addition either way; doubled for a truncating
+// adder). If g is in the chain top-k then s~_g >= T - 2 eps_q (the k rows of the MFMA top-k have chain scores
+// >= T - eps_q, hence the k-th best chain score is >= T - eps_q), so with delta_q = 6.4e-5 * max(1, |q|) * 1.01 (gallery rows
+// are unit vectors: cosine similarity) the short list contains every row of the exact answer, tau_q - delta_q admits all
+// of them in pass C, and the output (scores AND indices) is bit-identical to ranking the chain scores of the whole shard.
+// Overflows (a stream list, the LDS candidate buffer or the short list: pathological score distributions such as tens of
+// thousands of identical rows) are detected ON THE DEVICE: sim_final flags the query and the gated list kernels
+// (sim_topk_v2 + sim_topk_merge, launched behind it, a few microseconds when idle) recompute exactly those queries:
+// no host synchronisation, no process-global mode.
+constexpr float SIM_DELTA = 6.4e-5f * 1.01f;
+constexpr int FS_MAX = 8192;                           // candidates per query held in LDS by sim_final (64 KiB)
+constexpr int SL_MAX = 512;                            // short list (re-scored exactly)
+constexpr int SCAN_NS = 8, SCAN_AHEAD = 7;             // LDS-DMA ring of 16-KiB gallery tiles: 128 KiB, one block per CU
+
 struct ScanArgs {
   int Bq, Ng, nqg, nsplit, tiles_per_split;
-  long row_stride;                 // gallery rows between consecutive scanned rows (DENSE sample: > 1)
-  int n_rows;                      // rows scanned (DENSE: S; APPEND: Ng)
-  float* dense; long dense_ld;     // DENSE: out[q * dense_ld + j]
+  int ntiles;                      // tiles this launch walks (SAMPLE: sample tiles; APPEND: all tiles)
+  int tile_stride;                 // gallery tiles between consecutive walked tiles (SAMPLE: >= 1; APPEND: 1)
+  float* pmax; int ngroups;        // SAMPLE: pmax[q * ngroups + split * 2 + h]
   const float* tau; int* cnt; float* cand_s; int* cand_i; int cap;   // APPEND
 };
 
-template <typename TG, bool DENSE>
-__global__ void __launch_bounds__(256, 2) sim_scan(const float* __restrict__ Q, const TG* __restrict__ G, const ScanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 16 KiB gallery tiles
-  constexpr int C = 256, TILE = 32 * C * 2;
+// One block = 8 waves = 256 * QB queries (wave w owns queries q0 + 32 * QB * w ..): with QB = 2 all 512 queries of an
+// 8-GPU all-gather (8 x 64) sit in ONE block, so every gallery byte is fetched from HBM once per launch (512 MB at 1M rows)
+// and the kernel is MFMA-bound (arithmetic intensity = queries per block FLOP/B against a ridge of ~400); the K-fragments of
+// the wave's queries stay in registers for the whole kernel (QB * 64 VGPRs) and each A fragment read from LDS feeds QB MFMAs.
+// Gallery tiles (32 rows x 512 B) stream through an 8-slot LDS-DMA ring, 7 tiles (112 KiB per CU) in flight: counted
+// s_waitcnt vmcnt, one barrier per tile. The LDS image is lane-linear per wave-instruction (64 lanes x 16 B = two 512-B
+// rows), so slot (row, sl) is fed from source chunk sl ^ (row & 15) and the reads apply the same XOR (conflict-free b128).
+template <typename TG, int QB, bool SAMPLE>
+__global__ void __launch_bounds__(512, 2) sim_scan(const float* __restrict__ Q, const TG* __restrict__ G, const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int C = 256, TILE = 32 * C * 2, NS = SCAN_NS, AHEAD = SCAN_AHEAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int qg = blockIdx.x % a.nqg, split = blockIdx.x / a.nqg;
-  const int q0 = qg * 256 + wave * 64;
-  const bool active = q0 < a.Bq;
+  const int q0 = qg * (256 * QB) + wave * (32 * QB);
+  const bool active = q0 < a.Bq;                     // wave-uniform: idle waves still stage and barrier
 
-  uint4 qf[2][16];
-  float tau[2] = {0.f, 0.f};
-  int ncand[2] = {0, 0};
+  uint4 qf[QB][16];
+  float tau[QB], gmax[QB];
+  int ncand[QB];
   const int nstreams = a.nsplit * 2;
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     const int q = min(q0 + qb * 32 + r, a.Bq - 1);
     const float* qrow = Q + (long)q * C;
 #pragma unroll
     for (int c = 0; c < 16; ++c) qf[qb][c] = q_frag16<TG>(qrow, c, h);
-    if (!DENSE) tau[qb] = a.tau[q];
+    tau[qb] = SAMPLE ? 0.f : a.tau[q];
+    gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
-  // Gallery stream: LDS-DMA ring of NS 16-KiB tiles, AHEAD tiles in flight (80 KiB per CU): with one tile in flight the
-  // scan ran at HBM LATENCY (16 KiB per ~4.5 us per CU = 0.9 TB/s chip-wide). The LDS image is lane-linear per wave
-  // (64 lanes x 16 B = two 512-B rows), so slot (row, sl) is fed from source chunk sl ^ (row & 15).
-  constexpr int NS = 4, AHEAD = 3;                 // 64 KiB of LDS: two blocks (8 waves) per CU
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
-  const unsigned wbase = __builtin_amdgcn_readfirstlane(tid & ~63) * 16;       // this wave's first slot (bytes) per 4-KiB pass
-  int st_row[4], st_src[4];
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(tid & ~63) * 16;       // this wave's first slot (bytes) per 8-KiB pass
+  int st_row[2], st_src[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, row = c >> 5, sl = c & 31;
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 512 * i, row = c >> 5, sl = c & 31;
     st_row[i] = row; st_src[i] = (sl ^ (row & 15)) * 8;
   }
-  int rd[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) rd[c] = r * 512 + (((2 * c + h) ^ (r & 15)) << 4);
+  // read address of K-step c: row r, chunk (2c + h) ^ (r & 15) = ((c ^ (r>>1 & 7)) << 1) | ((h ^ r) & 1): one XOR per read instead
+  // of 16 address registers (the APPEND form otherwise spills, and a spill reload drains the LDS-DMA ring: vmcnt(0))
+  const int rd_base = r * 512 + (((h ^ r) & 1) << 4), rd_x = (r >> 1) & 7;
+#define SIM_RD(c_) (rd_base + ((((c_) ^ rd_x)) << 5))
 
-  const int ntiles = cdiv(a.n_rows, 32);
-  const int t0 = split * a.tiles_per_split, t1 = min(t0 + a.tiles_per_split, ntiles);
+  const int t0 = split * a.tiles_per_split, t1 = min(t0 + a.tiles_per_split, a.ntiles);
   auto issue = [&](int t) {
-    const int g0 = t * 32;
+    const long g0 = (long)t * a.tile_stride * 32;
     const unsigned dst = lds0 + ((t - t0) % NS) * TILE + wbase;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      glds16(G + (long)min(g0 + st_row[i], a.n_rows - 1) * a.row_stride * C + st_src[i], dst + 256 * 16 * i);
+    for (int i = 0; i < 2; ++i)
+      glds16(G + min(g0 + st_row[i], (long)a.Ng - 1) * C + st_src[i], dst + 512 * 16 * i);
   };
   for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
   for (int t = t0; t < t1; ++t) {
-    // tile t has landed once at most 4 * (tiles issued after t) of this wave's DMA are still outstanding
+    // tile t has landed once at most 2 * (tiles issued after t) of this wave's DMA are still outstanding (VMEM retires in
+    // order; candidate stores issued in between only make the wait stricter)
     const int later = min(t1 - 1 - t, AHEAD - 1);
     switch (later) {
-      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
-    __syncthreads();                                   // every wave's part of tile t is in LDS; tile t-1 is fully consumed
+    __builtin_amdgcn_s_barrier();                      // every wave's part of tile t is in LDS; tile t-1 is fully consumed
     if (t + AHEAD < t1) issue(t + AHEAD);              // -> ring slot of tile t-1
     const char* buf = smem + ((t - t0) % NS) * TILE;
     if (active) {
-      f32x16 acc[2];
+      f32x16 acc[QB];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-      // A fragments two K-steps ahead of the MFMAs that consume them (one wave per SIMD: no other wave hides LDS latency)
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[qb][e] = 0.f;
+      // A fragments four K-steps ahead of the MFMAs that consume them
       uint4 af[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + rd[c]);
+      for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + SIM_RD(c));
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const uint4 av = af[c & 3];
-        if (c + 4 < 16) af[c & 3] = *(const uint4*)(buf + rd[c + 4]);
-        if (__is_same(TG, bf16_t)) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[0][c]), acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[1][c]), acc[1], 0, 0, 0);
-        } else {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[0][c]), acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[1][c]), acc[1], 0, 0, 0);
+        if (c + 4 < 16) af[c & 3] = *(const uint4*)(buf + SIM_RD(c + 4));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          if (__is_same(TG, bf16_t))
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][c]), acc[qb], 0, 0, 0);
+          else
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][c]), acc[qb], 0, 0, 0);
         }
       }
-      const int g0 = t * 32;
+      const long g0 = (long)t * a.tile_stride * 32;
+      const bool ragged = g0 + 32 > a.Ng;              // wave-uniform: only the shard's last tile
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const int q = q0 + qb * 32 + r;
-        if (DENSE) {
-          if (q < a.Bq) {
+      for (int qb = 0; qb < QB; ++qb) {
+        if (ragged) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int g = g0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              if (g < a.n_rows) a.dense[(long)q * a.dense_ld + g] = acc[qb][e];
-            }
-          }
-        } else {
-          float tmax = -INFINITY;
+          for (int e = 0; e < 16; ++e)
+            if (g0 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.Ng) acc[qb][e] = -INFINITY;   // clamped duplicate rows never count
+        }
+        float tmax = fmaxf(fmaxf(acc[qb][0], acc[qb][1]), fmaxf(acc[qb][2], acc[qb][3]));
 #pragma unroll
-          for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, acc[qb][e]);
-          if (__builtin_amdgcn_ballot_w64(tmax >= tau[qb]) != 0) {             // rare after the sample threshold
+        for (int e = 4; e < 16; e += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(acc[qb][e], acc[qb][e + 1]), fmaxf(acc[qb][e + 2], acc[qb][e + 3])));
+        if (SAMPLE) {
+          gmax[qb] = fmaxf(gmax[qb], tmax);
+        } else if (__builtin_amdgcn_ballot_w64(tmax >= tau[qb]) != 0) {          // rare after the sample threshold
+          const int q = q0 + qb * 32 + r;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int g = g0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              if (acc[qb][e] >= tau[qb] && g < a.n_rows && q < a.Bq) {
-                // private list of this (query, gallery slice, lane half): a register counter, no atomic round trip
-                // (a returning atomicAdd per accepted score serialised ~2 us each: 7x the MFMA time at 1M rows)
-                if (ncand[qb] < a.cap) {
-                  const long o = ((long)q * nstreams + split * 2 + h) * a.cap + ncand[qb];
-                  a.cand_s[o] = acc[qb][e]; a.cand_i[o] = g;
-                }
-                ++ncand[qb];
+          for (int e = 0; e < 16; ++e) {
+            if (acc[qb][e] >= tau[qb] && acc[qb][e] > -INFINITY && q < a.Bq) {     // (-inf = masked row beyond the shard; tau may be -inf)
+              if (ncand[qb] < a.cap) {
+                const long o = ((long)q * nstreams + split * 2 + h) * a.cap + ncand[qb];
+                a.cand_s[o] = acc[qb][e]; a.cand_i[o] = (int)g0 + (e & 3) + 8 * (e >> 2) + 4 * h;
               }
+              ++ncand[qb];
             }
           }
         }
       }
     }
   }
-  if (!DENSE && active) {
+  if (active) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       const int q = q0 + qb * 32 + r;
-      if (q < a.Bq) a.cnt[(long)q * nstreams + split * 2 + h] = ncand[qb];
+      if (q < a.Bq) {
+        if (SAMPLE) a.pmax[(long)q * a.ngroups + split * 2 + h] = gmax[qb];
+        else a.cnt[(long)q * nstreams + split * 2 + h] = ncand[qb];
+      }
     }
   }
 }
 
-// k-th best of each query's S sample scores -> tau (block per query; k rounds of block-wide max with removal in LDS)
-__global__ void __launch_bounds__(256) sim_sample_tau(const float* dense, long ld, int S, int k, float* tau, int* cnt) {
-  extern __shared__ __attribute__((aligned(16))) float sv[];
-  __shared__ float rs[4]; __shared__ int rp[4];
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < S; i += 256) sv[i] = dense[(long)q * ld + i];
-  (void)cnt;
-  __syncthreads();
-  float kth = -INFINITY;
-  for (int round = 0; round < k; ++round) {
-    float bs = -INFINITY; int bp = -1;
-    for (int i = tid; i < S; i += 256) if (bp < 0 || sv[i] > bs) { bs = sv[i]; bp = i; }
+#undef SIM_RD
+
+template <typename TG> __device__ __forceinline__ float round_to(float x);
+template <> __device__ __forceinline__ float round_to<bf16_t>(float x) { return bf2f(f2bf(x)); }
+template <> __device__ __forceinline__ float round_to<_Float16>(float x) { return (float)(_Float16)x; }
+
+// tau_q = (k-th largest of the query's group maxima) - delta_q ; one wave per query, ngroups <= 512 (8 values per lane).
+// ngroups < k (or no sample at all: ngroups == 0) gives -inf: every row is then a candidate.
+template <typename TG>
+__global__ void __launch_bounds__(256) sim_tau(const float* __restrict__ Q, const float* __restrict__ pmax, int ngroups, int Bq, int k,
+                                               float* tau, int* flags, int* ovf_q) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0;          // per-call overflow flag (read by the gated fallback kernels)
+  if (q >= Bq) return;
+  if (lane == 0) ovf_q[q] = 0;
+  float nrm = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float os = __shfl_xor(bs, o, 64); const int op = __shfl_xor(bp, o, 64);
-      if (op >= 0 && (bp < 0 || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
+  for (int i = 0; i < 4; ++i) { const float v = round_to<TG>(Q[(long)q * 256 + lane * 4 + i]); nrm = fmaf(v, v, nrm); }
+  nrm = sqrtf(wave_sum(nrm));
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (lane + 64 * i < ngroups) ? pmax[(long)q * ngroups + lane + 64 * i] : -INFINITY;
+  float kth = -INFINITY;
+  if (ngroups >= k) {
+    for (int round = 0; round < k; ++round) {
+      float m = v[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) m = fmaxf(m, v[i]);
+      kth = wave_max(m);
+      // remove ONE instance of the maximum: the first lane holding it clears its first copy
+      const unsigned long long owners = __builtin_amdgcn_ballot_w64(m == kth);
+      if (lane == __builtin_ctzll(owners)) {
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (!done && v[i] == kth) { v[i] = -INFINITY; done = true; }
+      }
     }
-    if (lane == 0) { rs[wave] = bs; rp[wave] = bp; }
-    __syncthreads();
-    if (tid == 0) {
-      float fs = rs[0]; int fp = rp[0];
-      for (int w = 1; w < 4; ++w) if (rp[w] >= 0 && (fp < 0 || rs[w] > fs || (rs[w] == fs && rp[w] < fp))) { fs = rs[w]; fp = rp[w]; }
-      rs[0] = fs;
-      if (fp >= 0) sv[fp] = -INFINITY;
-    }
-    __syncthreads();
-    kth = rs[0];
-    __syncthreads();
   }
-  if (tid == 0) tau[q] = (S >= k) ? kth : -INFINITY;
+  if (lane == 0) tau[q] = kth - SIM_DELTA * fmaxf(1.f, nrm);      // -inf stays -inf
 }
 
-// exact top-k of a query's candidates (nstreams private lists of <= cap entries), (score desc, index asc).
-// The lists are first compacted into LDS (LDS atomic slot counter), then k rounds of block-wide arg-best run on-chip.
-constexpr int FS_MAX = 8192;                           // candidates per query held in LDS (64 KiB)
-__global__ void __launch_bounds__(256) sim_final_select(const float* cand_s, const int* cand_i, const int* cnt, int nstreams, int cap,
-                                                        int k, long long g_offset, float* out_s, long long* out_i) {
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+// D. exact top-k of one query's candidates. LDS: cs/ci [FS_MAX] | sl_s/sl_i [SL_MAX] | qs[256] | hist[256].
+template <typename TG>
+__global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, const TG* __restrict__ G, const float* cand_s, const int* cand_i,
+                                                 const int* cnt, int nstreams, int cap, int k, long long g_offset, float* out_s,
+                                                 long long* out_i, int* flags, int* ovf_q, int no_fallback) {
   extern __shared__ __attribute__((aligned(16))) char fsraw[];
   float* cs = (float*)fsraw; int* ci = (int*)(cs + FS_MAX);
-  __shared__ float rs[4]; __shared__ int ri[4]; __shared__ int rp[4]; __shared__ int ovf, total;
+  float* sl_s = (float*)(ci + FS_MAX); int* sl_i = (int*)(sl_s + SL_MAX);
+  float* qs = (float*)(sl_i + SL_MAX); int* hist = (int*)(qs + 256);
+  __shared__ int ovf, total, nsl, sel_bin, k_rem;
+  __shared__ float qn2[4];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { ovf = 0; total = 0; }
+  if (tid == 0) { ovf = 0; total = 0; nsl = 0; }
+  const float qv = round_to<TG>(Q[(long)q * 256 + tid]);          // the query as the MFMA saw it
+  qs[tid] = qv;
+  const float part = wave_sum(qv * qv);
+  if (lane == 0) qn2[wave] = part;
   __syncthreads();
+  const float delta = SIM_DELTA * fmaxf(1.f, sqrtf(qn2[0] + qn2[1] + qn2[2] + qn2[3]));
+  // 1. compaction of the private stream lists
   for (int st = tid; st < nstreams; st += 256) {
     const int c = cnt[(long)q * nstreams + st];
     if (c > cap) ovf = 1;
@@ -475,37 +529,103 @@ __global__ void __launch_bounds__(256) sim_final_select(const float* cand_s, con
   __syncthreads();
   if (total > FS_MAX) ovf = 1;
   const int n = min(total, FS_MAX);
-  const bool overflow = ovf != 0;
   __syncthreads();
-  for (int round = 0; round < k; ++round) {
-    float bs = -INFINITY; int bi = INT_MAX, bp = -1;
-    for (int i = tid; i < n; i += 256) {
-      if (ci[i] == INT_MAX) continue;                  // already taken
-      if (bp < 0 || cs[i] > bs || (cs[i] == bs && ci[i] < bi)) { bs = cs[i]; bi = ci[i]; bp = i; }
-    }
+  // 2. T = k-th best MFMA score (4-pass radix select over order-preserving keys); n <= k: every candidate is in
+  float T = -INFINITY;
+  if (!ovf && n > k) {
+    unsigned prefix = 0;
+    if (tid == 0) k_rem = k;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += 256) {
+        const unsigned key = f2key(cs[i]);
+        if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (wave == 0) {                                   // bins 4*lane .. 4*lane+3; suffix sums from the top bin down
+        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const int mine = h0 + h1 + h2 + h3;
+        int above = mine;                                // inclusive suffix sum over lanes >= this one
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float os = __shfl_xor(bs, o, 64); const int oi = __shfl_xor(bi, o, 64), op = __shfl_xor(bp, o, 64);
-      if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(above, o, 64); if (lane + o < 64) above += t; }
+        above -= mine;                                   // elements in bins above this lane's four
+        const int kr = k_rem;
+        if (above < kr && kr <= above + mine) {          // exactly one lane
+          int a3 = above, b = 3;
+          if (kr <= a3 + h3) b = 3; else { a3 += h3; if (kr <= a3 + h2) b = 2; else { a3 += h2; if (kr <= a3 + h1) b = 1; else { a3 += h1; b = 0; } } }
+          sel_bin = 4 * lane + b; k_rem = kr - a3;
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | (unsigned)sel_bin;
+      __syncthreads();
     }
-    if (lane == 0) { rs[wave] = bs; ri[wave] = bi; rp[wave] = bp; }
-    __syncthreads();
-    if (tid == 0) {
-      float fs = rs[0]; int fi = ri[0], fp = rp[0];
-      for (int w = 1; w < 4; ++w) if (rp[w] >= 0 && (fp < 0 || rs[w] > fs || (rs[w] == fs && ri[w] < fi))) { fs = rs[w]; fi = ri[w]; fp = rp[w]; }
-      out_s[(long)q * k + round] = fp >= 0 ? fs : -INFINITY;
-      out_i[(long)q * k + round] = overflow ? -2LL : (fp >= 0 ? (long long)fi + g_offset : -1LL);
-      if (fp >= 0) ci[fp] = INT_MAX;
-    }
-    __syncthreads();
+    const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    T = __uint_as_float(u);
   }
+  // 3. short list: MFMA score >= T - delta
+  if (!ovf) {
+    const float cut = T - delta;
+    for (int i = tid; i < n; i += 256) {
+      if (cs[i] >= cut) {
+        const int p = atomicAdd(&nsl, 1);
+        if (p < SL_MAX) sl_i[p] = ci[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (nsl > SL_MAX) ovf = 1;
+  __syncthreads();
+  if (ovf) {                                             // flag the query; the gated list kernels behind recompute it
+    if (tid == 0) { ovf_q[q] = 1; atomicOr(flags, 1); }
+    for (int j = tid; j < k; j += 256) { out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -2LL; }
+    (void)no_fallback;
+    return;
+  }
+  const int m = nsl;
+  // 4. exact re-scoring: the fmaf chain of oracle/c/sim_chain.c (chunk c = 0..31 of 8: k = 8c+i then 8c+4+i, i = 0..3)
+  for (int j = tid; j < m; j += 256) {
+    const uint4* row = (const uint4*)(G + (long)sl_i[j] * 256);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < 32; ++c) {
+      const uint4 v = row[c];
+      float g[8];
+      if (__is_same(TG, bf16_t)) {
+        g[0] = __uint_as_float(v.x << 16); g[1] = __uint_as_float(v.x & 0xffff0000u); g[2] = __uint_as_float(v.y << 16); g[3] = __uint_as_float(v.y & 0xffff0000u);
+        g[4] = __uint_as_float(v.z << 16); g[5] = __uint_as_float(v.z & 0xffff0000u); g[6] = __uint_as_float(v.w << 16); g[7] = __uint_as_float(v.w & 0xffff0000u);
+      } else {
+        const f16x8 hv = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = (float)hv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc = fmaf(g[i], qs[8 * c + i], acc);
+        acc = fmaf(g[4 + i], qs[8 * c + 4 + i], acc);
+      }
+    }
+    sl_s[j] = acc;
+  }
+  __syncthreads();
+  // 5. rank by (chain score desc, index asc); entries beyond the short list (Ng < k) are (-inf, -1)
+  for (int j = tid; j < m; j += 256) {
+    const float s = sl_s[j]; const int idx = sl_i[j];
+    int rank = 0;
+    for (int i = 0; i < m; ++i) rank += (sl_s[i] > s || (sl_s[i] == s && sl_i[i] < idx)) ? 1 : 0;
+    if (rank < k) { out_s[(long)q * k + rank] = s; out_i[(long)q * k + rank] = (long long)idx + g_offset; }
+  }
+  for (int j = m + tid; j < k; j += 256) { out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -1LL; }
 }
 
 __device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
 
 // one block per query: k rounds of block-wide arg-best over nparts*KMAX candidates held in LDS.
 __global__ void __launch_bounds__(256) sim_topk_merge(const float* ws_s, const int* ws_i, int n, int k, long long g_offset,
-                                                      float* out_s, long long* out_i) {
+                                                      float* out_s, long long* out_i, const int* gate_q) {
+  if (gate_q && gate_q[blockIdx.x] == 0) return;                // fallback: only the queries whose candidate lists overflowed
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   float* cs = (float*)smraw; int* ci = (int*)(cs + n);
   __shared__ float rs[4]; __shared__ int ri[4]; __shared__ int rp[4];
@@ -535,102 +655,131 @@ __global__ void __launch_bounds__(256) sim_topk_merge(const float* ws_s, const i
   }
 }
 
-int g_topk_force_lists = 0;       // cor_topk_set_mode(1): always use the per-lane list kernels (fallback after an overflow)
-constexpr int V3_MIN_ROWS = 32768;
-struct V3Plan { int S, stride, cap, nsplit, tiles_per_split, nstreams; };
-int device_cus();
-inline V3Plan make_v3(int Bq, int Ng, int k, int) {
-  V3Plan p;
-  p.S = 4096;
-  p.stride = Ng / p.S;                                 // strided sample: robust to ordered galleries
-  const int nqg = cdiv(Bq, 256), tiles = cdiv(Ng, 32);
-  int want = 2 * device_cus() / nqg;                   // two resident blocks per CU
-  if (want > tiles) want = tiles;
+inline int device_cus() { return cor_device_cus(); }
+
+// plan of the threshold-and-append pipeline (host; shared by the launcher and cor_topk_workspace_bytes)
+struct V3Plan {
+  int qb, nqg;                       // query blocks per wave (1 | 2), query groups of 256 * qb
+  int tiles, nsplit, tiles_per_split, nstreams, cap;                 // APPEND pass
+  int s_stride, s_tiles, s_nsplit, s_tiles_per_split, ngroups;       // SAMPLE pass (ngroups == 0: no sample, tau = -inf)
+  size_t off_pmax, off_tau, off_flags, off_ovf, off_cnt, off_cs, off_ci, off_lists, bytes;
+};
+inline V3Plan make_v3(int Bq, int Ng, int k) {
+  V3Plan p{};
+  p.qb = Bq > 256 ? 2 : 1;
+  p.nqg = cdiv(Bq, 256 * p.qb);
+  p.tiles = cdiv(Ng, 32);
+  int want = device_cus() / p.nqg;                     // one resident block per CU
+  if (want > 256) want = 256;                          // nstreams <= 512 (sim_tau holds 8 group maxima per lane)
+  if (want > p.tiles) want = p.tiles;
   if (want < 1) want = 1;
-  p.tiles_per_split = cdiv(tiles, want);
-  p.nsplit = cdiv(tiles, p.tiles_per_split);
+  p.tiles_per_split = cdiv(p.tiles, want);
+  p.nsplit = cdiv(p.tiles, p.tiles_per_split);
   p.nstreams = 2 * p.nsplit;
-  const long expect = (long)k * Ng / p.S / p.nstreams;  // expected accepted scores per private list
-  p.cap = (int)(4 * expect + 32);
+  long expect;                                         // expected accepted scores per query over the whole shard
+  if (Ng <= 4096) {                                    // tiny shard: no sample pass, every row is a candidate (<= FS_MAX)
+    p.ngroups = 0; p.s_tiles = 0; p.s_stride = 1; p.s_nsplit = 0; p.s_tiles_per_split = 0;
+    p.cap = 16 * p.tiles_per_split;
+  } else {
+    p.s_stride = p.tiles / 16 >= 128 ? 16 : (p.tiles / 128 > 1 ? p.tiles / 128 : 1);   // every 16th tile, at least ~128 sample tiles
+    p.s_tiles = cdiv(p.tiles, p.s_stride);
+    int sw = device_cus() / p.nqg;
+    if (sw > 256) sw = 256;
+    if (sw > p.s_tiles) sw = p.s_tiles;
+    if (sw < 1) sw = 1;
+    p.s_tiles_per_split = cdiv(p.s_tiles, sw);
+    p.s_nsplit = cdiv(p.s_tiles, p.s_tiles_per_split);
+    p.ngroups = 2 * p.s_nsplit;
+    expect = 3L * k * p.s_stride;                      // ~ k * Ng / sample rows, x3 for group-maximum slack
+    p.cap = (int)(4 * expect / p.nstreams) + 24;
+  }
+  const TopkPlan2 p2 = make_plan2(Bq, Ng, k, device_cus());
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
+  p.off_pmax = take((size_t)Bq * (p.ngroups > 0 ? p.ngroups : 1) * 4);
+  p.off_tau = take((size_t)Bq * 4);
+  p.off_flags = take(16);
+  p.off_ovf = take((size_t)Bq * 4);
+  p.off_cnt = take((size_t)Bq * p.nstreams * 4);
+  p.off_cs = take((size_t)Bq * p.nstreams * p.cap * 4);
+  p.off_ci = take((size_t)Bq * p.nstreams * p.cap * 4);
+  p.off_lists = take((size_t)Bq * p2.nparts * p2.kmax * 8);          // fallback list kernels
+  p.bytes = o;
   return p;
 }
 
-int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    (void)hipGetDevice(&dev);
-    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return n;
-}
-
-int launch_merge(const float* ws_s, const int* ws_i, int Bq, int n, int k, long long g_offset, float* out_s, long long* out_i, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sim_topk_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(sim_topk_merge, dim3(Bq), dim3(256), (size_t)n * 8, s, ws_s, ws_i, n, k, g_offset, out_s, out_i);
+int launch_merge(const float* ws_s, const int* ws_i, int Bq, int n, int k, long long g_offset, float* out_s, long long* out_i,
+                 const int* gate_q, hipStream_t s) {
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)sim_topk_merge, 8192 * 8, once);
+  hipLaunchKernelGGL(sim_topk_merge, dim3(Bq), dim3(256), (size_t)n * 8, s, ws_s, ws_i, n, k, g_offset, out_s, out_i, gate_q);
   COR_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename TG>
-int launch_topk(const float* Q, const void* G, int Bq, int Ng, int C, int k, long long g_offset, float* out_s, long long* out_i,
-                void* workspace, hipStream_t s) {
-  float* ws_s = (float*)workspace;
-  if (sizeof(TG) == 2 && C == 256 && Ng >= V3_MIN_ROWS && !g_topk_force_lists) {   // threshold-and-append (exact)
-    const V3Plan p = make_v3(Bq, Ng, k, device_cus());
-    const size_t lds = 4 * 32 * 256 * 2;                // NS ring slots
-    static bool scan_attr = false;
-    if (!scan_attr) {
-      (void)hipFuncSetAttribute((const void*)sim_scan<TG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)sim_scan<TG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      scan_attr = true;
-    }
-    char* w = (char*)workspace;
-    float* dense = (float*)w; w += (size_t)Bq * p.S * 4;
-    float* tau = (float*)w; w += (size_t)Bq * 4;
-    int* cnt = (int*)w; w += (size_t)Bq * p.nstreams * 4;
-    float* cand_s = (float*)w; w += (size_t)Bq * p.nstreams * p.cap * 4;
-    int* cand_i = (int*)w;
-    ScanArgs a{};
-    a.Bq = Bq; a.Ng = Ng; a.nqg = cdiv(Bq, 256);
-    // 1. dense scores of a strided sample
-    a.row_stride = p.stride; a.n_rows = p.S; a.dense = dense; a.dense_ld = p.S;
-    { const int tiles = cdiv(p.S, 32); int want = device_cus() / a.nqg; if (want > tiles) want = tiles; if (want < 1) want = 1;
-      a.tiles_per_split = cdiv(tiles, want); a.nsplit = cdiv(tiles, a.tiles_per_split); }
-    hipLaunchKernelGGL((sim_scan<TG, true>), dim3(a.nqg * a.nsplit), dim3(256), lds, s, Q, (const TG*)G, a);
-    COR_CHECK_LAUNCH();
-    // 2. tau_q = k-th best sample score
-    hipLaunchKernelGGL(sim_sample_tau, dim3(Bq), dim3(256), (size_t)p.S * 4, s, dense, (long)p.S, p.S, k, tau, cnt);
-    COR_CHECK_LAUNCH();
-    // 3. full scan: every (query, slice, lane half) stream keeps the scores >= tau_q in its private list
-    a.row_stride = 1; a.n_rows = Ng; a.tau = tau; a.cnt = cnt; a.cand_s = cand_s; a.cand_i = cand_i; a.cap = p.cap;
-    a.tiles_per_split = p.tiles_per_split; a.nsplit = p.nsplit;
-    hipLaunchKernelGGL((sim_scan<TG, false>), dim3(a.nqg * a.nsplit), dim3(256), lds, s, Q, (const TG*)G, a);
-    COR_CHECK_LAUNCH();
-    // 4. exact selection
-    static bool fs_attr = false;
-    if (!fs_attr) {
-      (void)hipFuncSetAttribute((const void*)sim_final_select, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX * 8);
-      fs_attr = true;
-    }
-    hipLaunchKernelGGL(sim_final_select, dim3(Bq), dim3(256), FS_MAX * 8, s, cand_s, cand_i, cnt, p.nstreams, p.cap, k, g_offset, out_s, out_i);
-    COR_CHECK_LAUNCH();
-    return 0;
-  }
-  if (sizeof(TG) == 2 && C == 256) {                   // MFMA-bound form
-    const TopkPlan2 p = make_plan2(Bq, Ng, k, device_cus());
-    int* ws_i = (int*)(ws_s + (long)Bq * p.nparts * p.kmax);
-    const dim3 grid(p.nqg * p.nsplit), block(256);
-    const size_t lds = 2 * 32 * 256 * 2;
-#define SIM_V2(KM) hipLaunchKernelGGL((sim_topk_v2<TG, KM>), grid, block, lds, s, Q, (const TG*)G, Bq, Ng, p, ws_s, ws_i)
-    if (p.kmax == 8) SIM_V2(8); else if (p.kmax == 16) SIM_V2(16); else SIM_V2(32);
+int launch_lists_v2(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_offset, float* out_s, long long* out_i, float* ws_s,
+                    const int* gate, const int* gate_q, hipStream_t s) {
+  const TopkPlan2 p = make_plan2(Bq, Ng, k, device_cus());
+  int* ws_i = (int*)(ws_s + (long)Bq * p.nparts * p.kmax);
+  const dim3 grid(p.nqg * p.nsplit), block(256);
+  const size_t lds = 2 * 32 * 256 * 2;
+#define SIM_V2(KM) hipLaunchKernelGGL((sim_topk_v2<TG, KM>), grid, block, lds, s, Q, G, Bq, Ng, p, ws_s, ws_i, gate)
+  if (p.kmax == 8) SIM_V2(8); else if (p.kmax == 16) SIM_V2(16); else SIM_V2(32);
 #undef SIM_V2
+  COR_CHECK_LAUNCH();
+  return launch_merge(ws_s, ws_i, Bq, p.nparts * p.kmax, k, g_offset, out_s, out_i, gate_q, s);
+}
+
+template <typename TG, int QB>
+int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_offset, float* out_s, long long* out_i, char* w,
+              const V3Plan& p, int flags, hipStream_t s) {
+  constexpr size_t lds = (size_t)SCAN_NS * 32 * 256 * 2;
+  static DevOnce once_s, once_a, once_f;
+  cor_max_dyn_lds((const void*)sim_scan<TG, QB, true>, (int)lds, once_s);
+  cor_max_dyn_lds((const void*)sim_scan<TG, QB, false>, (int)lds, once_a);
+  constexpr size_t fs_lds = (size_t)FS_MAX * 8 + SL_MAX * 8 + 256 * 4 + 256 * 4;
+  cor_max_dyn_lds((const void*)sim_final<TG>, (int)fs_lds, once_f);
+  float* pmax = (float*)(w + p.off_pmax); float* tau = (float*)(w + p.off_tau);
+  int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
+  float* cand_s = (float*)(w + p.off_cs); int* cand_i = (int*)(w + p.off_ci);
+  ScanArgs a{};
+  a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg;
+  if (p.ngroups > 0) {                                  // A. group maxima of the strided sample
+    a.nsplit = p.s_nsplit; a.tiles_per_split = p.s_tiles_per_split; a.ntiles = p.s_tiles; a.tile_stride = p.s_stride;
+    a.pmax = pmax; a.ngroups = p.ngroups;
+    hipLaunchKernelGGL((sim_scan<TG, QB, true>), dim3(p.nqg * p.s_nsplit), dim3(512), lds, s, Q, G, a);
     COR_CHECK_LAUNCH();
-    return launch_merge(ws_s, ws_i, Bq, p.nparts * p.kmax, k, g_offset, out_s, out_i, s);
+  }
+  // B. tau (ngroups == 0: -inf) ; also clears the per-call overflow flags
+  hipLaunchKernelGGL((sim_tau<TG>), dim3(cdiv(Bq, 4)), dim3(256), 0, s, Q, pmax, p.ngroups, Bq, k, tau, dflags, ovf_q);
+  COR_CHECK_LAUNCH();
+  // C. full scan
+  a.nsplit = p.nsplit; a.tiles_per_split = p.tiles_per_split; a.ntiles = p.tiles; a.tile_stride = 1;
+  a.tau = tau; a.cnt = cnt; a.cand_s = cand_s; a.cand_i = cand_i; a.cap = p.cap;
+  hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, Q, G, a);
+  COR_CHECK_LAUNCH();
+  // D. exact selection
+  hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, cand_s, cand_i, cnt, p.nstreams, p.cap, k, g_offset, out_s, out_i,
+                     dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
+  COR_CHECK_LAUNCH();
+  if (flags & COR_TOPK_NO_FALLBACK) return 0;           // overflowed queries keep index -2 (tests)
+  // E. gated fallback: the list kernels exit at once unless sim_final flagged an overflow
+  return launch_lists_v2<TG>(Q, G, Bq, Ng, k, g_offset, out_s, out_i, (float*)(w + p.off_lists), dflags, ovf_q, s);
+}
+
+template <typename TG>
+int launch_topk(const float* Q, const void* G, int Bq, int Ng, int C, int k, long long g_offset, float* out_s, long long* out_i,
+                void* workspace, int flags, hipStream_t s) {
+  float* ws_s = (float*)workspace;
+  const bool force_lists = (flags & COR_TOPK_FORCE_LISTS) != 0;
+  if constexpr (sizeof(TG) == 2) {
+    if (C == 256 && !force_lists) {                     // threshold-and-append + exact re-scoring
+      const V3Plan p = make_v3(Bq, Ng, k);
+      if (p.qb == 2) return launch_v3<TG, 2>(Q, (const TG*)G, Bq, Ng, k, g_offset, out_s, out_i, (char*)workspace, p, flags, s);
+      return launch_v3<TG, 1>(Q, (const TG*)G, Bq, Ng, k, g_offset, out_s, out_i, (char*)workspace, p, flags, s);
+    }
+    if (C == 256) return launch_lists_v2<TG>(Q, (const TG*)G, Bq, Ng, k, g_offset, out_s, out_i, ws_s, nullptr, nullptr, s);
   }
   const TopkPlan p = make_plan(Bq, Ng, k);
   int* ws_i = (int*)(ws_s + (long)Bq * p.nparts * p.kmax);
@@ -638,15 +787,10 @@ int launch_topk(const float* Q, const void* G, int Bq, int Ng, int C, int k, lon
   if (p.kmax == 8) hipLaunchKernelGGL((sim_topk_partial<TG, 8>), dim3(cdiv(nwaves, 4)), dim3(256), 0, s, Q, (const TG*)G, Bq, Ng, C, p, ws_s, ws_i);
   else hipLaunchKernelGGL((sim_topk_partial<TG, 32>), dim3(cdiv(nwaves, 4)), dim3(256), 0, s, Q, (const TG*)G, Bq, Ng, C, p, ws_s, ws_i);
   COR_CHECK_LAUNCH();
-  return launch_merge(ws_s, ws_i, Bq, p.nparts * p.kmax, k, g_offset, out_s, out_i, s);
+  return launch_merge(ws_s, ws_i, Bq, p.nparts * p.kmax, k, g_offset, out_s, out_i, nullptr, s);
 }
 
 }  // namespace
-
-extern "C" int cor_topk_set_mode(int force_lists) {
-  g_topk_force_lists = force_lists ? 1 : 0;
-  return 0;
-}
 
 extern "C" long cor_topk_workspace_bytes(int Bq, int Ng, int k) {
   if (Bq <= 0 || Ng <= 0 || k <= 0 || k > 32) return COR_EINVAL;
@@ -654,24 +798,20 @@ extern "C" long cor_topk_workspace_bytes(int Bq, int Ng, int k) {
   const TopkPlan2 p2 = make_plan2(Bq, Ng, k, device_cus());
   const long a = (long)Bq * p.nparts * p.kmax * 8, b = (long)Bq * p2.nparts * p2.kmax * 8;
   long m = a > b ? a : b;
-  if (Ng >= V3_MIN_ROWS) {
-    const V3Plan v = make_v3(Bq, Ng, k, 0);
-    const long c = (long)Bq * v.S * 4 + (long)Bq * 4 + (long)Bq * v.nstreams * 4 + (long)Bq * v.nstreams * v.cap * 8;
-    if (c > m) m = c;
-  }
-  return m;
+  const long c = (long)make_v3(Bq, Ng, k).bytes;
+  return c > m ? c : m;
 }
 
 extern "C" int cor_similarity_topk(const float* Q, const void* G, int g_dtype, int Bq, int Ng, int C, int k, long long g_offset,
-                                   float* out_scores, long long* out_idx, void* workspace, void* stream) {
+                                   float* out_scores, long long* out_idx, void* workspace, int flags, void* stream) {
   if (!Q || !G || !out_scores || !out_idx || !workspace || Bq <= 0 || Ng <= 0 || k <= 0) return COR_EINVAL;
   if (k > 32 || C > 256 || (C & 15)) return COR_ENOSUPPORT;
-  if (((uintptr_t)Q & 15) || ((uintptr_t)G & 15)) return COR_EINVAL;
+  if (((uintptr_t)Q & 15) || ((uintptr_t)G & 15) || ((uintptr_t)workspace & 255)) return COR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   switch (g_dtype) {
-    case COR_F32: return launch_topk<float>(Q, G, Bq, Ng, C, k, g_offset, out_scores, out_idx, workspace, s);
-    case COR_BF16: return launch_topk<bf16_t>(Q, G, Bq, Ng, C, k, g_offset, out_scores, out_idx, workspace, s);
-    case COR_F16: return launch_topk<_Float16>(Q, G, Bq, Ng, C, k, g_offset, out_scores, out_idx, workspace, s);
+    case COR_F32: return launch_topk<float>(Q, G, Bq, Ng, C, k, g_offset, out_scores, out_idx, workspace, flags, s);
+    case COR_BF16: return launch_topk<bf16_t>(Q, G, Bq, Ng, C, k, g_offset, out_scores, out_idx, workspace, flags, s);
+    case COR_F16: return launch_topk<_Float16>(Q, G, Bq, Ng, C, k, g_offset, out_scores, out_idx, workspace, flags, s);
     default: return COR_ENOSUPPORT;
   }
 }

@@ -213,8 +213,11 @@ __global__ void __launch_bounds__(256) embed_kernel(const long long* ids, const 
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int r = (int)(i / (D >> 2)), c = (int)(i - (long)r * (D >> 2)) * 4;
     long long id = ids[r];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // clamp: an out-of-range id must not fault the GPU
-    const f32x4 e = *(const f32x4*)(table + id * D + c), p = *(const f32x4*)(pos + (long)(r % ctx) * D + c);
+    const bool oob = id < 0 || id >= vocab;              // nn.Embedding raises here (a wrong tokenizer: SigLIP vs SigLIP2 vocabulary);
+    id = oob ? 0 : id;                                   // no fault, but no plausible garbage either: the row becomes NaN and poisons
+    f32x4 e = *(const f32x4*)(table + id * D + c);       // that sample's text feature visibly
+    const f32x4 p = *(const f32x4*)(pos + (long)(r % ctx) * D + c);
+    if (oob) { const float q = __builtin_nanf(""); e = f32x4{q, q, q, q}; }
     *(f32x4*)(out + (long)r * D + c) = e + p;
   }
 }

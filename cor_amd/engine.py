@@ -234,7 +234,7 @@ def siglip_vision(W, img, g, T, p="support_branch.siglip.model.visual.trunk."):
     cols = ops.patchify(img, g["patch"], W[p + "patch.K"], T)
     x = ops.gemm(cols, W[p + "patch_embed.proj.weight"], out_dtype=F32, bias=W[p + "patch_embed.proj.bias"],
                  residual=W[p + "pos_embed"], res_row_mod=P)
-    act = _gelu(g["gelu"])
+    act = _gelu(g.get("v_gelu", g.get("gelu", "erf")))
     for i in range(g["depth"]):
         b = f"{p}blocks.{i}."
         h = _ln(W, b + "norm1.", x, 1e-6, T)
@@ -253,7 +253,7 @@ def siglip_text(W, tokens, g, T, p="support_branch.siglip.model.text."):
     N, ctx = tokens.shape
     D = g["dim"]
     x = ops.embed_tokens(tokens.contiguous(), W[p + "token_embedding.weight"], W[p + "positional_embedding"])
-    act = _gelu(g["gelu"])
+    act = _gelu(g.get("t_gelu", g.get("gelu", "erf")))
     for i in range(g["t_depth"]):
         b = f"{p}transformer.resblocks.{i}."
         h = _ln(W, b + "ln_1.", x, 1e-6, T)

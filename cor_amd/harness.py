@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import contextlib
 import csv
+import functools
 import os
 import time
 from datetime import datetime, timedelta
@@ -54,6 +55,18 @@ def _dev(model):
     return getattr(model, "device", None) or next(model.parameters()).device
 
 
+def _on_model_device(fn):
+    """Run a harness loop with the model's GPU as the current device (the HIP kernels are enqueued on the current device)."""
+    @functools.wraps(fn)
+    def wrapped(test_loader, model, *a, **k):
+        dev = _dev(model)
+        if dev.type != "cuda":
+            raise RuntimeError("cor_amd harness: the model must live on a GPU (there is no CPU path)")
+        with torch.cuda.device(dev):
+            return fn(test_loader, model, *a, **k)
+    return wrapped
+
+
 def postprocess_masks(pred_mask: torch.Tensor) -> torch.Tensor:
     """sigmoid -> per-sample min-max. ref: utils/vailder.py:426-430. [B,1,H,W] logits -> [B,1,H,W] in [0,1]."""
     return ops.mask_prob_minmax(pred_mask)
@@ -64,6 +77,7 @@ def compute_metrics(pred: torch.Tensor, gt: torch.Tensor, smooth: float = 1e-5) 
     return ops.mask_metrics(pred, gt, smooth)
 
 
+@_on_model_device
 @torch.no_grad()
 def save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, dataset_path="/data/dataset", pred_save_dir="predictions"):
     from PIL import Image
@@ -124,6 +138,7 @@ def _item(v):
     return v.item() if torch.is_tensor(v) else v
 
 
+@_on_model_device
 @torch.no_grad()
 def val_metric(test_loader, model, opt, logger, accelerator=None, output_csv_name="per_sample_metrics.csv"):
     model.eval()

@@ -50,8 +50,20 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
             return torch.bfloat16      # the reference runs inference under accelerator.autocast() bf16 (vaild_a.yaml:4)
         return self.compute_dtype
 
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("cor_amd: the model must live on a GPU (model.to('cuda')); there is no CPU path")
+
+    def _fingerprint(self):
+        """Cheap change detector for the packed-weight cache: every in-place update (optimizer step, p.data.copy_, a
+        submodule's load_state_dict) bumps the tensor's _version; re-allocation (.to(), .half()) changes data_ptr."""
+        return hash(tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers())))
+
     def packed(self, T=None):
         T = T or self._resolve_dtype()
+        fp = self._fingerprint()
+        if self._packed.get("fp") != fp:
+            self._packed = {"fp": fp}
         if T not in self._packed:
             with torch.no_grad():
                 self._packed[T] = engine.pack(self.state_dict(), self.image_encoder.cfg, self.support_branch.siglip.cfg,
@@ -65,15 +77,19 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
             raise RuntimeError("cor_amd implements the retrieval-time (inference) forward only: call model.eval() first "
                                "(training / backward are out of scope)")
         T = self._resolve_dtype()
-        return engine.forward(self.packed(T), self.image_encoder.cfg, self.support_branch.siglip.cfg,
-                              self.support_branch.mask_pooling_name, T, query_image_inputs, support_image_inputs,
-                              change_text_inputs, support_mask_inputs, multimask_output)
+        self._require_gpu()
+        with torch.cuda.device(self.device):       # the kernels launch on the CURRENT device: make it the model's
+            return engine.forward(self.packed(T), self.image_encoder.cfg, self.support_branch.siglip.cfg,
+                                  self.support_branch.mask_pooling_name, T, query_image_inputs, support_image_inputs,
+                                  change_text_inputs, support_mask_inputs, multimask_output)
 
     @torch.no_grad()
     def forward_with_aux(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
                          multimask_output=True):
         """forward() plus {'masks': all 4 mask logits, 'iou': [B,4], 'best': [B]} for parity tests / analysis."""
         T = self._resolve_dtype()
-        return engine.forward(self.packed(T), self.image_encoder.cfg, self.support_branch.siglip.cfg,
-                              self.support_branch.mask_pooling_name, T, query_image_inputs, support_image_inputs,
-                              change_text_inputs, support_mask_inputs, multimask_output, return_aux=True)
+        self._require_gpu()
+        with torch.cuda.device(self.device):
+            return engine.forward(self.packed(T), self.image_encoder.cfg, self.support_branch.siglip.cfg,
+                                  self.support_branch.mask_pooling_name, T, query_image_inputs, support_image_inputs,
+                                  change_text_inputs, support_mask_inputs, multimask_output, return_aux=True)

@@ -119,7 +119,7 @@ class SigLIP(nn.Module):
     def __init__(self, model_name: str = "ViT-SO400M-14-SigLIP-384", pretrained: str = None, cfg: dict = None,
                  with_map_head: bool = True):
         super().__init__()
-        self.cfg = dict(cfg) if cfg is not None else config.siglip_cfg(model_name)
+        self.cfg = config.normalize_siglip_cfg(dict(cfg)) if cfg is not None else config.siglip_cfg(model_name)
         self.model = _ClipModel(self.cfg, with_map_head)
         self.text_tokenizer = None            # the reference resolves an HF-hub tokenizer by name; not available offline
         if pretrained is not None:            # open_clip checkpoints are a plain state_dict of `model`

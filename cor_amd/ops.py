@@ -35,9 +35,24 @@ def _p(t):
 
 
 def _dev(*ts):
+    """Host-side guard run BEFORE every launch: the kernels take raw pointers and are enqueued on the CURRENT device's
+    current stream, so (1) no CPU tensor, (2) all operands on ONE GPU, (3) that GPU is the current HIP device (otherwise
+    the launch would dereference another device's memory: a GPU fault). Callers holding a model on another device wrap
+    the call in `with torch.cuda.device(model.device)` (CirSegModelWithQuerySupportFeat.forward does)."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("cor_amd ops run on the GPU only (no CPU fallback): got a CPU tensor")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"cor_amd ops: operands live on different devices ({dev} and {t.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"cor_amd ops: operands live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"wrap the call in `with torch.cuda.device({dev.index})`")
+    return dev
 
 
 def _rows(t: torch.Tensor):
@@ -52,8 +67,8 @@ def _f32vec(t, n, name):
     assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, f"{name}: need contiguous fp32[{n}]"
 
 
-def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual=None, res_row_mod=0, out=None):
-    """out[M,N] = residual + col_scale * act(a[M,K] @ w[N,K]^T + bias)."""
+def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual=None, res_row_mod=0, out=None, cfg=0):
+    """out[M,N] = residual + col_scale * act(a[M,K] @ w[N,K]^T + bias). cfg: per-call kernel choice (0 = automatic)."""
     _dev(a, w, bias, col_scale, residual, out)
     M, K, lda = _rows(a)
     N, K2, ldw = _rows(w)
@@ -73,7 +88,7 @@ def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     nat.check(_lib().cor_gemm(a.data_ptr(), lda, w.data_ptr(), ldw, _dt(a), out.data_ptr(), ldc, _dt(out), M, N, K,
-                              _p(bias), act, _p(col_scale), _p(residual), ldr, res_row_mod, _s()), "cor_gemm")
+                              _p(bias), act, _p(col_scale), _p(residual), ldr, res_row_mod, int(cfg), _s()), "cor_gemm")
     if prof is not None:
         e1.record()
         nbytes = (M * K + N * K) * a.element_size() + M * N * out.element_size() + (M * N * 4 if residual is not None else 0)
@@ -108,7 +123,7 @@ def attention(q, k, v, B, H, Tq, Tk, hd, scale, out_dtype=None):
     return out
 
 
-def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None):
+def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None, variant=0):
     _dev(qkv, pad_row, rel_h, rel_w)
     hd = rel_h.shape[1]
     d = H * hd
@@ -120,7 +135,7 @@ def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None
         assert pad_row is not None and pad_row.dtype == qkv.dtype and pad_row.is_contiguous() and pad_row.numel() == 3 * d
     out = torch.empty((B * grid * grid, d), dtype=out_dtype or qkv.dtype, device=qkv.device)
     nat.check(_lib().cor_sam_attention(qkv.data_ptr(), _dt(qkv), out.data_ptr(), _dt(out), _p(pad_row), rel_h.data_ptr(),
-                                       rel_w.data_ptr(), B, H, hd, grid, window, _s()), "cor_sam_attention")
+                                       rel_w.data_ptr(), B, H, hd, grid, window, int(variant), _s()), "cor_sam_attention")
     return out
 
 
@@ -341,8 +356,11 @@ def iou_select(iou, hyper, k_off, Ksel):
     return best, sel
 
 
-def similarity_topk(Q, G, k, g_offset=0, check_overflow=True):
-    """Top-k gallery rows per query by dot product; (score desc, index asc). Q fp32 [Bq,C]; G [Ng,C] fp32/bf16/fp16."""
+def similarity_topk(Q, G, k, g_offset=0, flags=0):
+    """Top-k gallery rows per query by dot product; (score desc, index asc). Q fp32 [Bq,C]; G [Ng,C] fp32/bf16/fp16.
+    fp32 galleries and 16-bit galleries with C = 256: scores and indices are bit-identical to the CPU fmaf-chain oracle
+    (oracle/c/sim_chain.c). A candidate overflow (pathological score distributions) is repaired ON THE DEVICE by the gated
+    list kernels: no host synchronisation here. flags: nat.TOPK_FORCE_LISTS | nat.TOPK_NO_FALLBACK (tests)."""
     _dev(Q, G)
     assert Q.dtype == torch.float32 and Q.is_contiguous() and G.is_contiguous() and Q.dim() == 2 and G.dim() == 2
     Bq, Cq = Q.shape
@@ -352,19 +370,11 @@ def similarity_topk(Q, G, k, g_offset=0, check_overflow=True):
     nbytes = lib.cor_topk_workspace_bytes(Bq, Ng, k)
     if nbytes < 0:
         nat.check(int(nbytes), "cor_topk_workspace_bytes")
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=Q.device)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=Q.device)          # torch's allocator returns >= 256-B aligned blocks
     scores = torch.empty((Bq, k), dtype=torch.float32, device=Q.device)
     idx = torch.empty((Bq, k), dtype=torch.int64, device=Q.device)
     nat.check(lib.cor_similarity_topk(Q.data_ptr(), G.data_ptr(), _dt(G), Bq, Ng, Cq, k, int(g_offset), scores.data_ptr(),
-                                      idx.data_ptr(), ws.data_ptr(), _s()), "cor_similarity_topk")
-    if check_overflow and Ng >= 32768 and G.dtype != torch.float32 and bool((idx[:, 0] == -2).any()):
-        # candidate-list overflow of the threshold-and-append path (pathological score distribution): exact list kernels
-        lib.cor_topk_set_mode(1)
-        try:
-            nat.check(lib.cor_similarity_topk(Q.data_ptr(), G.data_ptr(), _dt(G), Bq, Ng, Cq, k, int(g_offset), scores.data_ptr(),
-                                              idx.data_ptr(), ws.data_ptr(), _s()), "cor_similarity_topk")
-        finally:
-            lib.cor_topk_set_mode(0)
+                                      idx.data_ptr(), ws.data_ptr(), int(flags), _s()), "cor_similarity_topk")
     return scores, idx
 
 

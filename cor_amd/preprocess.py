@@ -75,6 +75,11 @@ def resize_to_tensor(img: torch.Tensor, out_h: int, out_w: int, mean=None, std=N
     H, W, C = a.shape
     if C not in (1, 3):
         raise ValueError("C must be 1 or 3")
+    with torch.cuda.device(a.device):                # raw-pointer launches go to the CURRENT device: make it the image's
+        return _resize_to_tensor(a, H, W, C, out_h, out_w, mean, std, return_u8)
+
+
+def _resize_to_tensor(a, H, W, C, out_h, out_w, mean, std, return_u8):
     lib = nat.load()
     dev = a.device
     if W != out_w:                                   # Pillow: the horizontal pass runs first when the width changes

@@ -8,8 +8,8 @@ Order: score descending, then global gallery index ascending.
 Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU tests):
 the gallery is row-sharded, rank r owning rows [r*ceil(G/R), ...). One exchange step on the data path: an
 all-gather of the [B_local, 256] query embeddings (<= 64 KB per rank: latency-bound). Each rank then scores
-ALL queries against its shard with the HIP kernel (cor_similarity_topk), and the per-shard (score, global index)
-lists ([B_total, k] each) are gathered and merged on the host by (score desc, index asc).
+ALL queries against its shard with the HIP kernel (cor_similarity_topk), and the packed per-shard (score, global index)
+lists go to one rank in ONE gather and are merged once on the host by (score desc, index asc).
 """
 from __future__ import annotations
 
@@ -54,8 +54,9 @@ class GalleryShard:
 
     def search(self, queries: torch.Tensor, k: int):
         """queries f32[Bq,C] (unit-norm) -> (scores f32[Bq,k], global idx i64[Bq,k]) on the GPU."""
-        q = queries.reshape(-1, queries.shape[-1]).to(torch.float32).contiguous()
-        return ops.similarity_topk(q, self.rows, k, g_offset=self.offset)
+        q = queries.reshape(-1, queries.shape[-1]).to(self.rows.device, torch.float32).contiguous()
+        with torch.cuda.device(self.rows.device):
+            return ops.similarity_topk(q, self.rows, k, g_offset=self.offset)
 
 
 def shard_bounds(n_rows: int, world: int, rank: int):
@@ -64,31 +65,69 @@ def shard_bounds(n_rows: int, world: int, rank: int):
     return lo, min(lo + per, n_rows)
 
 
-def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int, group=None):
+def _pack_lists(s: torch.Tensor, i: torch.Tensor) -> torch.Tensor:
+    """(scores f32[B,k], idx i64[B,k]) -> ONE int32 tensor [B,k,3] (score bits, index lo, index hi): 12 B per entry."""
+    out = torch.empty(s.shape + (3,), dtype=torch.int32, device=s.device)
+    out[..., 0] = s.contiguous().view(torch.int32)
+    out[..., 1:] = i.contiguous().view(torch.int32).view(i.shape + (2,))
+    return out
+
+
+def _unpack_lists(p: torch.Tensor):
+    return p[..., 0].contiguous().view(torch.float32), p[..., 1:].contiguous().view(torch.int64).squeeze(-1)
+
+
+def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int, group=None, max_local: int | None = None,
+                       dst: int | None = 0):
     """All ranks call this with their own queries [B_local, C] and their gallery shard.
-    Returns on EVERY rank (scores f32[B_total,k], idx i64[B_total,k]) as CPU tensors, queries ordered by rank.
-    Collectives: all_gather(queries) on the device, all_gather_object-free gather of the small result lists."""
+
+    Two collectives in all, as BASELINE.json's north_star describes it:
+      1. ONE all-gather of the query embeddings over RCCL/xGMI (<= 64 KB per rank: latency-bound). The payload is a
+         fixed-size block [max_local + 1, C]: rows 0..B_local-1 are the queries, the last row carries B_local, so a ragged
+         last batch (B_local differing between ranks) is legal as long as every rank passes the same `max_local`
+         (a configuration constant, e.g. the loader's batch size; default: this rank's B_local, i.e. equal batches);
+      2. each rank scores ALL queries against its shard (cor_similarity_topk) and the packed per-shard lists
+         ([B_total,k,3] int32 = 12 B per entry) go to rank `dst` in ONE gather, where they are merged ONCE on the host
+         by (score desc, global index asc). dst=None: all-gather instead, every rank merges (the round-1 behaviour).
+    Returns (scores f32[B_total,k], idx i64[B_total,k]) CPU tensors, queries ordered by rank, on rank `dst` (every rank
+    for dst=None); (None, None) on the other ranks."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         s, i = shard.search(local_queries, k)
         return s.cpu(), i.cpu()
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     q = local_queries.reshape(-1, local_queries.shape[-1]).to(torch.float32).contiguous()
-    dev = q.device
+    b_local, C = q.shape
+    cap = int(max_local) if max_local is not None else b_local
+    if b_local > cap:
+        raise ValueError(f"distributed_search: {b_local} local queries exceed max_local={cap}")
+    dev = shard.rows.device
     host_coll = dist.get_backend(group) == "gloo"               # CPU rehearsal backend: collectives on host copies
-    if host_coll:
-        q = q.cpu()
-    gathered = [torch.empty_like(q) for _ in range(world)]
-    dist.all_gather(gathered, q, group=group)                    # the one data-path collective (RCCL over xGMI)
-    allq = torch.cat(gathered, dim=0).to(dev)
+    cdev = torch.device("cpu") if host_coll else dev
+    block = torch.zeros((cap + 1, C), dtype=torch.float32, device=cdev)
+    block[:b_local] = q.to(cdev)
+    block[cap, 0] = float(b_local)
+    allb = torch.empty((world * (cap + 1), C), dtype=torch.float32, device=cdev)
+    dist.all_gather_into_tensor(allb, block, group=group)        # collective 1 (RCCL over xGMI)
+    allb = allb.view(world, cap + 1, C)
+    counts = [int(c) for c in allb[:, cap, 0].tolist()]          # (the result lists go to the host anyway)
+    if any(c < 0 or c > cap for c in counts):
+        raise RuntimeError(f"distributed_search: inconsistent per-rank query counts {counts} for max_local={cap}")
+    allq = torch.cat([allb[r, :counts[r]] for r in range(world)], dim=0).to(dev)
     s, i = shard.search(allq, k)                                 # local shard vs ALL queries
-    if host_coll:
-        s, i = s.cpu(), i.cpu()
-    s_parts = [torch.empty_like(s) for _ in range(world)]
-    i_parts = [torch.empty_like(i) for _ in range(world)]
-    dist.all_gather(s_parts, s, group=group)                     # 12 B * B_total * k per rank
-    dist.all_gather(i_parts, i, group=group)
-    return merge_topk_host([t.cpu() for t in s_parts], [t.cpu() for t in i_parts], k)
+    packed = _pack_lists(s, i).to(cdev)
+    if dst is None:
+        parts = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=torch.int32, device=cdev)
+        dist.all_gather_into_tensor(parts, packed, group=group)  # collective 2 (all ranks merge)
+        parts = parts.view((world,) + tuple(packed.shape))
+    else:
+        glist = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+        dist.gather(packed, glist, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)   # collective 2
+        if rank != dst:
+            return None, None
+        parts = torch.stack(glist, dim=0)
+    ps, pi = _unpack_lists(parts.cpu())
+    return merge_topk_host(list(ps), list(pi), k)
 
 
 @torch.no_grad()

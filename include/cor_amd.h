@@ -23,6 +23,8 @@ extern "C" {
 
 #define COR_EINVAL (-1)
 #define COR_ENOSUPPORT (-2)
+#define COR_TOPK_FORCE_LISTS 1 /* cor_similarity_topk flags: per-lane sorted-list kernels only (no threshold-and-append) */
+#define COR_TOPK_NO_FALLBACK 2  /* ... : no device-side fallback after a candidate overflow: such queries return index -2 */
 
 enum { COR_F32 = 0, COR_BF16 = 1, COR_F16 = 2 /* gallery storage only */ };
 enum { COR_ACT_NONE = 0, COR_ACT_GELU_ERF = 1, COR_ACT_RELU = 2, COR_ACT_SIGMOID = 3, COR_ACT_GELU_TANH = 4 };
@@ -40,13 +42,12 @@ int cor_version(void);
 int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype,
              void* C, long ldc, int c_dtype, int M, int N, int K,
              const float* bias, int act, const float* col_scale,
-             const float* residual, long ldr, int res_row_mod, void* stream);
-
-/* Tuning knob for tools/gemm_bench.py: 0 = automatic choice (default: 13 for bf16 operands from 200 output tiles of 256x256
- * up, else 2, or 1 when K has a ragged tail); 1: 128x128 register-staged (any K); 2: 128x128 LDS-DMA; 9: 256x128, three LDS
- * buffers; 13: persistent 256x256 ping-pong kernel (bf16 operands; falls back to 2 / 1 where it does not apply); 14: the same
- * on 16x16x32 MFMAs. Values >= 100 set timing-only ablation / tile-order knobs (tools/gemm_ksweep.py). */
-int cor_gemm_set_config(int cfg);
+             const float* residual, long ldr, int res_row_mod, int cfg, void* stream);
+/* `cfg` is a PER-CALL kernel choice (no process-global state; safe from several threads / streams): 0 = automatic
+ * (13 for bf16 operands from 200 output tiles of 256x256 up, else 2, or 1 when K has a ragged tail); low byte 1: 128x128
+ * register-staged (any K); 2: 128x128 LDS-DMA; 3 / 4: 128x64 / 64x64; 9: 256x128, three LDS buffers; 13: persistent 256x256
+ * ping-pong kernel (bf16 operands; falls back to 2 / 1 where it does not apply); 14: the same on 16x16x32 MFMAs. Bits 8 and up:
+ * timing-only ablation / tile-order knobs of the persistent kernel (tools/gemm_ksweep.py); production callers pass 0. */
 
 /* y[r,:] = LayerNorm(x[r,:]) * w + b over the last dim, biased variance.
  * ref: nn.LayerNorm (image_encoder.py:169,183), LayerNorm2d common.py:31-43 and mask_adapter.py:226-251 (on
@@ -73,10 +74,10 @@ int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb,
  * out [B*grid*grid, H*hd]. rel_h / rel_w: [2S-1, hd] fp32.
  * ref: lib/sam_model/image_encoder.py:225-241 (Attention), :244-290 (window partition), :293-362 (rel-pos). */
 int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, const void* pad_row,
-                      const float* rel_h, const float* rel_w, int B, int H, int hd, int grid, int window, void* stream);
-
-/* Tuning knob (tools/attn_bench.py): global SAM attention kernel form, 0 = 32 queries per wave (default), 1 = 64 per wave. */
-int cor_flash_set_variant(int v);
+                      const float* rel_h, const float* rel_w, int B, int H, int hd, int grid, int window, int variant, void* stream);
+/* `variant` is a PER-CALL kernel choice for the bf16 MFMA path: 0 = default kernels (global: flash_global_pipe, software-
+ * pipelined over key tiles); 1 = the plain chain form of the same arithmetic (flash_fwd<1>), kept as the in-process A/B and
+ * parity partner (tests, tools/attn_bench.py). Production callers pass 0. */
 
 /* ---- data movement / elementwise --------------------------------------------------------------------------- */
 
@@ -102,7 +103,8 @@ int cor_nchw_to_tokens(const float* x, void* out, int out_dtype, int B, int HW, 
 /* y = x / max(||x||_2, eps) per row. ref: F.normalize (support_branch.py:85, cir_feature_fuse.py:58, siglip_openclip.py:56). */
 int cor_l2norm_rows(const void* x, int x_dtype, void* y, int y_dtype, int rows, int C, float eps, void* stream);
 
-/* out[r,:] = table[ids[r],:] + pos[r % ctx,:]. ref: open_clip TextTransformer embedding (siglip_openclip.py:53). */
+/* out[r,:] = table[ids[r],:] + pos[r % ctx,:]. An id outside [0, vocab) (nn.Embedding raises; a wrong tokenizer) makes the
+ * row NaN: never a fault, never plausible garbage. ref: open_clip TextTransformer embedding (siglip_openclip.py:53). */
 int cor_embed_tokens(const long long* ids, const float* table, const float* pos, float* out, int rows, int ctx, int D, int vocab, void* stream);
 
 /* ---- support branch (mask adapter, fusion) ------------------------------------------------------------------ */
@@ -198,12 +200,11 @@ int cor_resample_cols_u8(const unsigned char* in, float* out_f32, unsigned char*
  * The reference has no gallery/top-k code; the definition follows utils/loss_func.py:84 (cosine of unit vectors).
  * 16-bit shards of >= 32768 rows use threshold-and-append (a dense sample pass bounds each query's k-th best score,
  * the full pass appends the rare scores above it, exact selection over the candidates); if a query's candidate list
- * overflows (pathological score distributions) ALL its indices come back as -2: call cor_topk_set_mode(1) (per-lane
- * list kernels, always exact) and repeat. */
-int cor_topk_set_mode(int force_lists);
+ * overflows (pathological score distributions) ALL its indices come back as -2: repeat the call with
+ * flags = COR_TOPK_FORCE_LISTS (per-lane list kernels, always exact). `flags` is per call: no process-global state. */
 long cor_topk_workspace_bytes(int Bq, int Ng, int k);
 int cor_similarity_topk(const float* Q, const void* G, int g_dtype, int Bq, int Ng, int C, int k, long long g_offset,
-                        float* out_scores, long long* out_idx, void* workspace, void* stream);
+                        float* out_scores, long long* out_idx, void* workspace, int flags, void* stream);
 
 #ifdef __cplusplus
 }

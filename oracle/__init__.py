@@ -18,9 +18,11 @@ Parity status
   the reference's own modules imported in the build container
   (``tools/make_golden.py`` -> ``tests/golden/*.npz``; checked by
   ``tests/test_oracle_golden.py``).
-* Top-level glue (``SupportBranch.forward``, ``CirSegModel...forward``): the
-  reference files import ``open_clip`` (absent), so they are restated from the
-  source text and pinned only through their pinned parts.
+* Top-level glue (``SupportBranch.forward``, ``CirSegModel...forward``,
+  ``build_model_with_query_support_feat``): PINNED by ``tests/golden/toplevel_*.npz``,
+  outputs of the reference's own ``build_model...().forward`` on full SAM-B, run in the
+  build container through an in-memory ``open_clip`` stand-in (2-block SigLIP) by
+  ``tools/make_golden.py gen_toplevel``.
 * SigLIP towers (third-party ``open_clip_torch==2.31.0`` / ``timm==1.0.15``,
   not vendored, not installed): PARITY UNPINNED by the reference; restated from
   the published architecture and cross-checked against

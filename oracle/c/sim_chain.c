@@ -5,6 +5,9 @@
  * (MI355X guide, "FP32-input MFMA"). The kernel (cor_amd/csrc/retrieval.hip) feeds it 16-byte operand chunks, so for
  * chunk c = 0..C/8-1 and i = 0..3 the chain visits k = 8c+i and then k = 8c+4+i. This file walks the same chain with
  * fmaf(), so scores - and therefore top-k indices - can be compared BITWISE with the GPU.
+ * 16-bit galleries: the kernel's final selection re-scores its short list with this very chain over the stored bf16 / fp16
+ * values widened to fp32 and the query rounded to the gallery dtype (sim_final in retrieval.hip), so the same functions
+ * are the bitwise oracle there too (the caller passes the rounded / widened operands).
  *
  * The reference (wangtong627/COR) has no gallery scoring; the score definition is utils/loss_func.py:84
  * (F.cosine_similarity of unit vectors = dot product). */
@@ -24,5 +27,22 @@ void sim_chain_scores(const float* Q, const float* G, int Bq, int Ng, int C, flo
         }
       out[(size_t)b * Ng + g] = acc;
     }
+  }
+}
+
+/* Chain scores of selected (query, gallery row) pairs only: out[p] = chain(Q[qi[p]], G[gi[p]]). Lets the tests rank a
+ * 1M-row shard exactly without walking 512 x 1M chains: rows whose plain fp32 score is far below the k-th best cannot enter
+ * the chain top-k (the two summation orders differ by < 3.1e-5 for unit vectors), so only the near-top rows are chained. */
+void sim_chain_pairs(const float* Q, const float* G, const long long* qi, const long long* gi, long long n, int C, float* out) {
+  for (long long p = 0; p < n; ++p) {
+    const float* q = Q + (size_t)qi[p] * C;
+    const float* r = G + (size_t)gi[p] * C;
+    float acc = 0.0f;
+    for (int c = 0; c < C / 8; ++c)
+      for (int i = 0; i < 4; ++i) {
+        acc = fmaf(r[8 * c + i], q[8 * c + i], acc);
+        acc = fmaf(r[8 * c + 4 + i], q[8 * c + 4 + i], acc);
+      }
+    out[p] = acc;
   }
 }

@@ -18,15 +18,15 @@ SAM = {
 
 SIGLIP = {
     "ViT-B-16-SigLIP-384": dict(dim=768, depth=12, heads=12, mlp=3072, patch=16, image=384,
-                                vocab=32000, ctx=64, t_depth=12, t_heads=12, t_mlp=3072, gelu="erf"),
+                                vocab=32000, ctx=64, t_depth=12, t_heads=12, t_mlp=3072, v_gelu="erf", t_gelu="erf"),
     "ViT-B-16-SigLIP2-384": dict(dim=768, depth=12, heads=12, mlp=3072, patch=16, image=384,
-                                 vocab=256000, ctx=64, t_depth=12, t_heads=12, t_mlp=3072, gelu="tanh"),
+                                 vocab=256000, ctx=64, t_depth=12, t_heads=12, t_mlp=3072, v_gelu="tanh", t_gelu="tanh"),
     "ViT-L-16-SigLIP-384": dict(dim=1024, depth=24, heads=16, mlp=4096, patch=16, image=384,
-                                vocab=32000, ctx=64, t_depth=24, t_heads=16, t_mlp=4096, gelu="erf"),
+                                vocab=32000, ctx=64, t_depth=24, t_heads=16, t_mlp=4096, v_gelu="erf", t_gelu="erf"),
     "ViT-L-16-SigLIP2-384": dict(dim=1024, depth=24, heads=16, mlp=4096, patch=16, image=384,
-                                 vocab=256000, ctx=64, t_depth=24, t_heads=16, t_mlp=4096, gelu="tanh"),
+                                 vocab=256000, ctx=64, t_depth=24, t_heads=16, t_mlp=4096, v_gelu="tanh", t_gelu="tanh"),
     "ViT-SO400M-14-SigLIP-384": dict(dim=1152, depth=27, heads=16, mlp=4304, patch=14, image=384,
-                                     vocab=32000, ctx=64, t_depth=27, t_heads=16, t_mlp=4304, gelu="erf"),
+                                     vocab=32000, ctx=64, t_depth=27, t_heads=16, t_mlp=4304, v_gelu="erf", t_gelu="erf"),
 }
 
 

@@ -33,11 +33,7 @@ def scores_fma_chain(Q, G):
     __graft_entry__.build() into oracle/_build/libsimchain.so): bitwise comparable with cor_similarity_topk on an
     fp32 gallery. Q [Bq,C], G [Ng,C] float32 numpy arrays, C % 8 == 0."""
     import ctypes
-    import os
-    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libsimchain.so")
-    if not os.path.exists(so):
-        raise RuntimeError("oracle/_build/libsimchain.so missing: run python -c 'import __graft_entry__ as g; g.build()'")
-    lib = ctypes.CDLL(so)
+    lib = _chain_lib()
     Q = np.ascontiguousarray(Q, dtype=np.float32)
     G = np.ascontiguousarray(G, dtype=np.float32)
     assert Q.shape[1] == G.shape[1] and Q.shape[1] % 8 == 0
@@ -47,6 +43,47 @@ def scores_fma_chain(Q, G):
     lib.sim_chain_scores.restype = None
     lib.sim_chain_scores(Q.ctypes.data_as(fp), G.ctypes.data_as(fp), Q.shape[0], G.shape[0], Q.shape[1], out.ctypes.data_as(fp))
     return out
+
+
+def _chain_lib():
+    import ctypes
+    import os
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libsimchain.so")
+    if not os.path.exists(so):
+        raise RuntimeError("oracle/_build/libsimchain.so missing: run python -c 'import __graft_entry__ as g; g.build()'")
+    return ctypes.CDLL(so)
+
+
+def similarity_topk_chain(Q, G, k, chunk=64, margin=2e-4):
+    """EXACT top-k by the fmaf-chain score, (chain score desc, index asc), for shards too large to chain in full.
+    Q, G: float32 tensors holding the values the GPU multiplies (16-bit galleries: Q rounded to the gallery dtype, G widened).
+    Per query chunk: plain fp32 scores S = Q @ G.T, T = k-th best; every row with S >= T - margin is chained
+    (oracle/c/sim_chain.c: sim_chain_pairs) and ranked. A row of the chain top-k cannot be missed: |chain - S| < 3.1e-5 for
+    unit vectors (two fp32 summation orders of the same exact products), margin = 2e-4."""
+    import ctypes
+    lib = _chain_lib()
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong)
+    lib.sim_chain_pairs.argtypes = [fp, fp, ip, ip, ctypes.c_longlong, ctypes.c_int, fp]
+    lib.sim_chain_pairs.restype = None
+    Qn = np.ascontiguousarray(Q.float().numpy()); Gn = np.ascontiguousarray(G.float().numpy())
+    Bq, Ng = Qn.shape[0], Gn.shape[0]
+    kk = min(k, Ng)
+    rs = torch.empty((Bq, kk)); ri = torch.empty((Bq, kk), dtype=torch.int64)
+    Gt = torch.from_numpy(Gn)
+    for c0 in range(0, Bq, chunk):
+        S = torch.from_numpy(Qn[c0:c0 + chunk]) @ Gt.T
+        T = torch.topk(S, kk, dim=1).values[:, -1:]
+        qi, gi = (S >= T - margin).nonzero(as_tuple=True)
+        qi = np.ascontiguousarray((qi + c0).numpy().astype(np.int64)); gi = np.ascontiguousarray(gi.numpy().astype(np.int64))
+        out = np.empty(qi.shape[0], dtype=np.float32)
+        lib.sim_chain_pairs(Qn.ctypes.data_as(fp), Gn.ctypes.data_as(fp), qi.ctypes.data_as(ip), gi.ctypes.data_as(ip), qi.shape[0], Qn.shape[1],
+                            out.ctypes.data_as(fp))
+        order = np.lexsort((gi, -out.astype(np.float64), qi))          # by query, then chain score desc, then index asc
+        qi, gi, out = qi[order], gi[order], out[order]
+        starts = np.searchsorted(qi, np.arange(c0, min(c0 + chunk, Bq)))
+        for j, st in enumerate(starts):
+            rs[c0 + j] = torch.from_numpy(out[st:st + kk]); ri[c0 + j] = torch.from_numpy(gi[st:st + kk])
+    return rs, ri
 
 
 def similarity_topk(Q, G, k, exact_chain=False):

@@ -45,7 +45,7 @@ def vision_tokens(sd, x, cfg, p="support_branch.siglip.model.visual.trunk."):
     N = x.shape[0]
     t = patch_tokens(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"])
     t = t.reshape(N, -1, t.shape[-1]) + sd[p + "pos_embed"]
-    act = _act(cfg["gelu"])
+    act = _act(cfg.get("v_gelu", cfg.get("gelu", "erf")))        # per-tower GELU flavour (legacy key `gelu` = both)
     for i in range(cfg["depth"]):
         b = f"{p}blocks.{i}."
         h = _ln(sd, b + "norm1.", t, 1e-6)
@@ -67,7 +67,7 @@ def text_features(sd, tokens, cfg, p="support_branch.siglip.model.text.", normal
     """ref: lib/support_model/siglip_openclip.py:46-59 (+ open_clip TextTransformer, pool 'last').
     tokens int64 [N,64] -> [N,D]"""
     x = sd[p + "token_embedding.weight"][tokens] + sd[p + "positional_embedding"][: tokens.shape[1]]
-    act = _act(cfg["gelu"])
+    act = _act(cfg.get("t_gelu", cfg.get("gelu", "erf")))
     D = x.shape[-1]
     for i in range(cfg["t_depth"]):
         b = f"{p}transformer.resblocks.{i}."

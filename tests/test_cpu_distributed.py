@@ -26,23 +26,29 @@ class _OracleShard:
         return s, i
 
 
-def _worker(rank, world, port, G, Q_all, k, out):
+def _worker(rank, world, port, G, Q_all, k, split, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cor_amd import retrieval
         lo, hi = retrieval.shard_bounds(G.shape[0], world, rank)
         shard = _OracleShard(G[lo:hi], lo)
-        per = Q_all.shape[0] // world
-        s, i = retrieval.distributed_search(Q_all[rank * per:(rank + 1) * per], shard, k)
+        qlo, qhi = split[rank], split[rank + 1]                      # ragged per-rank batches are legal with max_local
+        cap = max(split[r + 1] - split[r] for r in range(world))
+        # (1) default: ONE gather to rank 0, merged once there; the other ranks get (None, None)
+        s, i = retrieval.distributed_search(Q_all[qlo:qhi], shard, k, max_local=cap)
         if rank == 0:
             out["s"], out["i"] = s, i
-        # every rank must hold the same merged answer
-        ref = [None]
-        if rank == 0:
-            ref = [(s, i)]
+        else:
+            assert s is None and i is None
+        # (2) dst=None: all-gather of the packed lists, every rank merges and must hold the same answer
+        s2, i2 = retrieval.distributed_search(Q_all[qlo:qhi], shard, k, max_local=cap, dst=None)
+        ref = [(out["s"], out["i"])] if rank == 0 else [None]
         dist.broadcast_object_list(ref, src=0)
-        assert torch.equal(ref[0][1], i) and torch.equal(ref[0][0], s)
+        assert torch.equal(ref[0][1], i2) and torch.equal(ref[0][0], s2)
+        # (3) more local queries than max_local must raise BEFORE any collective (same on every rank here)
+        with pytest.raises(ValueError):
+            retrieval.distributed_search(Q_all, shard, k, max_local=1)
     finally:
         dist.destroy_process_group()
 
@@ -53,8 +59,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("Ng,k", [(1000, 10), (7, 8)])
-def test_distributed_search_world2_gloo(Ng, k):
+def test_pack_unpack_lists_roundtrip():
+    from cor_amd import retrieval
+    s = torch.tensor([[1.5, float("-inf")], [-0.0, 3e-7]])
+    i = torch.tensor([[5, -1], [2 ** 40 + 3, -2]], dtype=torch.int64)
+    s2, i2 = retrieval._unpack_lists(retrieval._pack_lists(s, i))
+    assert torch.equal(s.view(torch.int32), s2.view(torch.int32)) and torch.equal(i, i2)
+
+
+@pytest.mark.parametrize("Ng,k,split", [(1000, 10, (0, 3, 6)), (7, 8, (0, 3, 6)), (1000, 10, (0, 4, 6)), (300, 5, (0, 6, 6))])
+def test_distributed_search_world2_gloo(Ng, k, split):
     from oracle import retrieval as oret
     gen = torch.Generator().manual_seed(0)
     G = torch.nn.functional.normalize(torch.randn((Ng, 256), generator=gen), dim=-1)
@@ -63,7 +77,7 @@ def test_distributed_search_world2_gloo(Ng, k):
     Q = torch.nn.functional.normalize(torch.randn((6, 256), generator=gen), dim=-1)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), G, Q, k, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), G, Q, k, split, out), nprocs=2, join=True)
     rs, ri = oret.similarity_topk(Q, G, k)
     kk = min(k, Ng)
     assert torch.equal(out["i"][:, :kk], ri) and torch.allclose(out["s"][:, :kk], rs)

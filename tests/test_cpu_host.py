@@ -93,3 +93,48 @@ def test_host_topk_merge_matches_oracle():
     assert torch.equal(i, full_i) and torch.allclose(s, full_s)
     s2, i2 = oret.merge_topk(list(zip(parts_s, parts_i)), 8)
     assert torch.equal(i2, full_i)
+
+
+def test_ops_refuse_operands_off_the_current_device(monkeypatch):
+    """kernels are enqueued with raw pointers on the CURRENT device's stream, so the host guard must refuse (before
+    any launch) operands on two devices, or on a device that is not the current one. No GPU here: tensor stand-ins."""
+    from cor_amd import ops
+
+    class T:
+        def __init__(self, index):
+            self.is_cuda, self.device = True, torch.device("cuda", index)
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    assert ops._dev(T(0), None, T(0)) == torch.device("cuda", 0)
+    with pytest.raises(RuntimeError, match="different devices"):
+        ops._dev(T(0), T(1))
+    with pytest.raises(RuntimeError, match="current device"):
+        ops._dev(T(1), T(1))
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        ops._dev(torch.zeros(1))
+
+
+def test_packed_cache_sees_submodule_and_inplace_updates():
+    """the packed-weight cache must notice a submodule load_state_dict and in-place parameter updates."""
+    from tests.test_gpu_parity import _build
+    from cor_amd import config
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=1, t_depth=1, vocab=64)
+    m = _build(1, (0,), gcfg, "MaskedPooling")
+    f0 = m._fingerprint()
+    assert m._fingerprint() == f0
+    with torch.no_grad():
+        m.mask_decoder.iou_token.weight.add_(1.0)                       # in-place (optimizer-step-like) update
+    f1 = m._fingerprint()
+    assert f1 != f0
+    m.image_encoder.load_state_dict(m.image_encoder.state_dict())      # submodule load: copy_ bumps every _version
+    assert m._fingerprint() != f1
+
+
+def test_siglip_cfg_per_tower_gelu():
+    from cor_amd import config
+    g = config.siglip_cfg("ViT-L-16-SigLIP2-384")
+    assert g["v_gelu"] == "tanh" and g["t_gelu"] == "tanh" and "gelu" not in g
+    g = config.normalize_siglip_cfg(dict(gelu="erf", t_gelu="tanh"))
+    assert g["v_gelu"] == "erf" and g["t_gelu"] == "tanh"
+    with pytest.raises(ValueError):
+        config.normalize_siglip_cfg(dict(v_gelu="swish"))

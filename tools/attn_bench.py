@@ -10,14 +10,13 @@ H, g, dev, T = 12, 64, "cuda:0", torch.bfloat16
 d = H * 64
 qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T)
 pad = torch.randn((3 * d,), device=dev).to(T)
-for window, S, variant in ((0, 64, 0), (0, 64, 1), (14, 14, 1)):
-    _native.load().cor_flash_set_variant(variant)
+for window, S, variant in ((0, 64, 0), (0, 64, 1), (14, 14, 0), (14, 14, 1)):   # variant: per-call kernel choice (0 = default)
     rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     ts = []
     for i in range(6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.sam_attention(qkv, pad, rh, rw, B, H, g, window); e1.record(); e1.synchronize()
+        e0.record(); ops.sam_attention(qkv, pad, rh, rw, B, H, g, window, variant=variant); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     fl = (4.0 * (g * g) ** 2 * 64 if window == 0 else 25 * 4.0 * 196 ** 2 * 64) * H * B
     print(json.dumps(dict(window=window, variant=variant, B=B, ms=min(ts[1:]), tflops=fl / (min(ts[1:]) * 1e-3) / 1e12)), flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One configuration of the SAM attention kernels, a few launches (for rocprofv3 --pmc passes):
-python tools/attn_one.py <global_variant> [B] [window]"""
+python tools/attn_one.py <variant: 0 default, 1 chain form> [B] [window]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +12,5 @@ d = H * 64
 S = 64 if window == 0 else 14
 qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T); pad = torch.randn((3 * d,), device=dev).to(T)
 rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5; rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
-_native.load().cor_flash_set_variant(variant)
-for i in range(3): ops.sam_attention(qkv, pad, rh, rw, B, H, g, window)
+for i in range(3): ops.sam_attention(qkv, pad, rh, rw, B, H, g, window, variant=variant)
 torch.cuda.synchronize()

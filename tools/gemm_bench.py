@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU micro-benchmark of cor_gemm tile configurations (cor_gemm_set_config) on the SAM-B / SigLIP-B shapes.
+"""GPU micro-benchmark of cor_gemm tile configurations (the per-call `cfg` argument) on the SAM-B / SigLIP-B shapes.
 Interleaved rounds in ONE process, random data (cdna guide rules 24/25). Checks every configuration against
 configuration 1 bit-for-bit tolerance-free on a sub-block (same accumulation order per k-step => tiny diffs only).
     python tools/gemm_bench.py [--cfgs 1 2 3 4 5 6] [--rounds 5]
@@ -32,6 +32,11 @@ SHAPES = [  # (M, N, K, act, residual, out_f32, label)
     (131072, 256, 256, 0, False, False, "decoder 256x256"),
 ]
 
+def enc(c):
+    """command-line cfg -> per-call cfg: kernel = c % 100, tile-order group = c // 100 (ablation bits 8.. of cfg)."""
+    return (c % 100) | ((16 * (c // 100)) << 8)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfgs", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6])
@@ -51,8 +56,7 @@ def main():
         od = torch.float32 if of32 else T
         outs, times = {}, {c: [] for c in a.cfgs}
         for c in a.cfgs:                                    # correctness + warm-up
-            _native.check(lib.cor_gemm_set_config(c % 100), "set_config"); lib.cor_gemm_set_config(100 + 16 * (c // 100))
-            outs[c] = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R)[:512].float().clone()
+            outs[c] = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R, cfg=enc(c))[:512].float().clone()
         torch.cuda.synchronize()
         ref = outs[a.cfgs[0]]
         errs = {c: float((outs[c] - ref).abs().max()) for c in a.cfgs}
@@ -62,10 +66,9 @@ def main():
         err_ref = float((ref - tref).abs().max())
         for _ in range(a.rounds):
             for c in a.cfgs:
-                lib.cor_gemm_set_config(c % 100); lib.cor_gemm_set_config(100 + 16 * (c // 100))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R)
+                ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R, cfg=enc(c))
                 e1.record(); e1.synchronize()
                 times[c].append(e0.elapsed_time(e1))
         fl = 2.0 * M * N * K
@@ -74,7 +77,6 @@ def main():
                                       tf_best=fl / (min(times[c]) * 1e-3) / 1e12, diff_vs_first=errs[c]) for c in a.cfgs})
         print(json.dumps(row), flush=True)
         res.append(row)
-    lib.cor_gemm_set_config(0); lib.cor_gemm_set_config(100)
 
 if __name__ == "__main__":
     main()

@@ -18,15 +18,13 @@ for (M, N, K) in SHAPES:
         W = (torch.randn((N, K), generator=g, device=dev) / K ** 0.5).to(T)
         bias = torch.randn((N,), generator=g, device=dev)
         R = torch.randn((M, N), generator=g, device=dev) if use_res else None
-        lib.cor_gemm_set_config(2); ref = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R).float()
-        lib.cor_gemm_set_config(cfg)
+        ref = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R, cfg=2).float()
         guard = torch.full((M + 2, N), 7.0, device=dev, dtype=od)            # rows before / after must stay untouched
-        out = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R, out=guard[1:M + 1])
+        out = ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R, out=guard[1:M + 1], cfg=cfg)
         torch.cuda.synchronize()
         d = float((out.float() - ref).abs().max())
         ok = d <= (0.07 if od == T else 1e-3) and bool((guard[0] == 7).all()) and bool((guard[M + 1] == 7).all())
         bad += not ok
         print(json.dumps(dict(shape=[M, N, K], out=str(od), act=act, res=use_res, maxdiff=d, ok=ok)), flush=True)
-lib.cor_gemm_set_config(0)
 print("FAILED" if bad else "ALL OK")
 sys.exit(1 if bad else 0)

@@ -16,21 +16,12 @@ for mode in ("bf16_out", "bf16_out_gelu", "f32_out_res"):
         act = 1 if mode.endswith("gelu") else 0
         row = dict(mode=mode, K=K)
         for c in cfgs:
-            if c >= 1400:
-                lib.cor_gemm_set_config(14); lib.cor_gemm_set_config(100 + c - 1400)
-            elif c >= 1300:
-                lib.cor_gemm_set_config(13); lib.cor_gemm_set_config(100 + c - 1300)
-            elif c >= 1200:
-                lib.cor_gemm_set_config(12); lib.cor_gemm_set_config(100 + c - 1200)
-            elif c >= 700:
-                lib.cor_gemm_set_config(7); lib.cor_gemm_set_config(100 + c - 700)
-            else:
-                lib.cor_gemm_set_config(c); lib.cor_gemm_set_config(100)
+            kern, knob = (c // 100, c % 100) if c >= 700 else (c, 0)      # 13xx = kernel 13 with ablation knob xx (per-call cfg)
+            cfg = kern | (knob << 8)
             ts = []
             for i in range(6):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R); e1.record(); e1.synchronize()
+                e0.record(); ops.gemm(A, W, out_dtype=od, bias=bias, act=act, residual=R, cfg=cfg); e1.record(); e1.synchronize()
                 ts.append(e0.elapsed_time(e1))
             row[f"cfg{c}_us"] = round(min(ts[1:]) * 1e3, 1)
         print(json.dumps(row), flush=True)
-lib.cor_gemm_set_config(0); lib.cor_gemm_set_config(100)

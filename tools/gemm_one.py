@@ -6,8 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops, _native
 M, N, K = (int(v) for v in sys.argv[1:4]); cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-lib = _native.load(); lib.cor_gemm_set_config(cfg)
 A = torch.randn((M, K), device="cuda").to(torch.bfloat16); W = (torch.randn((N, K), device="cuda") / K ** 0.5).to(torch.bfloat16)
 b = torch.randn((N,), device="cuda")
-for _ in range(5): ops.gemm(A, W, out_dtype=torch.bfloat16, bias=b)
+for _ in range(5): ops.gemm(A, W, out_dtype=torch.bfloat16, bias=b, cfg=cfg)
 torch.cuda.synchronize()

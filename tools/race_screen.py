@@ -18,16 +18,15 @@ for it in range(rounds):
         a = torch.randn((M, K), generator=g, device=dev).to(T); w = (torch.randn((N, K), generator=g, device=dev) / K ** 0.5).to(T)
         res = torch.randn((M, N), generator=g, device=dev)
         for od, r in ((T, None), (torch.float32, res)):
-            lib.cor_gemm_set_config(2); ref = ops.gemm(a, w, out_dtype=od, residual=r)
-            lib.cor_gemm_set_config(13); out = ops.gemm(a, w, out_dtype=od, residual=r)
+            ref = ops.gemm(a, w, out_dtype=od, residual=r, cfg=2)
+            out = ops.gemm(a, w, out_dtype=od, residual=r, cfg=13)
             if not torch.equal(out, ref):
                 bad += 1; print("GEMM MISMATCH", it, M, N, K, od, float((out.float() - ref.float()).abs().max()), flush=True)
-    lib.cor_gemm_set_config(0)
     B, H, gsz = 4, 12, 64
     qkv = torch.randn((B * gsz * gsz, 3 * H * 64), device=dev).to(T); pad = torch.randn((3 * H * 64,), device=dev).to(T)
     rh = torch.randn((127, 64), device=dev) * 0.5; rw = torch.randn((127, 64), device=dev) * 0.5
-    lib.cor_flash_set_variant(0); o0 = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
-    lib.cor_flash_set_variant(1); o1 = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
+    o0 = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0, variant=1).float()
+    o1 = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
     o1b = ops.sam_attention(qkv, pad, rh, rw, B, H, gsz, 0).float()
     d = float((o0 - o1).abs().max())
     if d > 0.05 or not torch.equal(o1, o1b) or not bool(torch.isfinite(o1).all()):
