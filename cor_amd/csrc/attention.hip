@@ -267,7 +267,7 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
                          long v_st, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale,
                          hipStream_t s);
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w,
-                       int B, int H, int grid, int window, int variant, hipStream_t s);
+                       int B, int H, int grid, int window, float q_prescale, int variant, hipStream_t s);
 
 extern "C" int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb,
                              long v_st, int dtype, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk,
@@ -310,14 +310,16 @@ static int sam_rowlane(AttnArgs a, int B, int grid, int window, int dtype, int o
 }
 
 extern "C" int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, const void* pad_row, const float* rel_h,
-                                 const float* rel_w, int B, int H, int hd, int grid, int window, int variant, void* stream) {
+                                 const float* rel_w, int B, int H, int hd, int grid, int window, float q_prescale, int variant, void* stream) {
   if (!qkv || !out || !rel_h || !rel_w || B <= 0 || H <= 0 || grid <= 0 || window < 0 || variant < 0) return COR_EINVAL;
+  if (!(q_prescale > 0.f)) return COR_EINVAL;
   if (window > 0 && !pad_row) return COR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == COR_BF16 && hd == 64) {
-    const int rc = cor_flash_sam_bf16(qkv, out, out_dtype, pad_row, rel_h, rel_w, B, H, grid, window, variant, s);
+    const int rc = cor_flash_sam_bf16(qkv, out, out_dtype, pad_row, rel_h, rel_w, B, H, grid, window, q_prescale, variant, s);
     if (rc != COR_ENOSUPPORT) return rc;
   }
+  if (q_prescale != 1.0f) return COR_ENOSUPPORT;       // the row-per-lane kernels take the raw q
   const int HD = hd;
   const long d = (long)H * HD;
   const size_t esz = dtype == COR_F32 ? 4 : 2;

@@ -27,7 +27,8 @@ struct FlashArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; void* o;
   long q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;   // MODE 0: element strides (batch, token)
   int H, Tq, Tk;
-  float scale_log2;                                     // softmax scale * log2(e)
+  float scale_log2;                                     // what (q . k) is multiplied by: softmax scale * log2(e) / q_prescale
+  float tbl_scale;                                      // what (Rtable . q) is multiplied by: log2(e) / q_prescale
   const bf16_t* pad_row; const float* rel_h; const float* rel_w;
   int grid, S, nW, d3;                                  // SAM: image grid, rel-pos size, windows per side, 3*H*64
   int nqt;                                              // query tiles (128 queries) per (batch, head)
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * LOG2E;
+          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
         if (tbl == 0) {
 #pragma unroll 4
           for (int i = 0; i < 32; ++i) {
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
                                                       __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) aux[tbl * 1024 + acc_row(e, h) * 32 + r] = acc[e] * LOG2E;
+      for (int e = 0; e < 16; ++e) aux[tbl * 1024 + acc_row(e, h) * 32 + r] = acc[e] * a.tbl_scale;
     }
     // column part of the bias for this lane's 32 score registers: constant over tiles -> registers
 #pragma unroll
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * LOG2E;
+          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
         if (tbl == 0) {
 #pragma unroll 4
           for (int i = 0; i < 32; ++i) {
@@ -675,6 +676,241 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   store_o_rows<TO>(o, inv, (char*)aux, (TO*)a.o, lane, off);       // the wave's row-bias table is dead: 8 KiB of private staging
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Windowed SAM attention (14x14 windows), ONE block per (window, head): 7 waves x 32 queries (224 slots for the 196 queries,
+// 12.5 % padding; flash_fwd<2> ran two 128-query blocks per (window, head): 23 % padding and every K/V byte staged twice).
+//   * K and V of the whole window (2 x 224 rows x 128 B = 56 KiB) are staged ONCE by LDS-DMA while the waves build their
+//     rel-pos tables; one barrier, then no synchronisation until the block ends;
+//   * LDS row R = 16 * kh + kw (kw = 14, 15: finite duplicates of kw = 13, masked through the bias), so the 32-key MFMA block
+//     `blk` holds window rows 2 blk and 2 blk + 1 and accumulator register e of lane half h is key (kh, kw) =
+//     (2 blk + (e >> 3), (e & 3) + 8 ((e >> 2) & 1) + 4 h): the row index is a compile-time property of the register, the
+//     column pattern is the same in every block -> 8 column-bias registers per lane for the whole kernel;
+//   * the softmax VALU bounds this kernel (196 keys amortise nothing), so the bias and the running reference are folded
+//     INTO the score MFMA: the accumulator is initialised with  colbias[kw] + rowbias[kh] - m  (one add per score; -inf
+//     for masked slots) and Q is pre-scaled by scale * log2(e), so the MFMA result is already  x - m  in the log2 domain
+//     and a score costs  add + max3/2 + exp2 + cvt_pk/2  instead of  fma + add + select + max + sub + exp2 + cvt_pk/2;
+//   * lazy rescaling as in the other kernels (reference moves only when a block maximum exceeds it by 2^8), row sums of P on
+//     the matrix pipe, P^T accumulators are directly the B operand of O^T += V^T . P^T, V^T by ds_read_b64_tr_b16.
+// LDS = 56 KiB K/V + 7 x 3456 B (per-wave rel-pos table, later the output staging) = 81536 B: two blocks (14 waves) per CU.
+// Where lanes of a wave exchange data through LDS, wavefront-scope fences tell hipcc so (no instruction is emitted).
+constexpr int WIN_ROWS = 224, WIN_KV = WIN_ROWS * 128, WIN_T = 27 * 32 * 4, WIN_LDS = 2 * WIN_KV + 7 * WIN_T;
+
+template <typename TO>
+__global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x % a.H, win = blockIdx.x / a.H;
+  const int nw2 = a.nW * a.nW, b = win / nw2, wi = win - b * nw2, wy = wi / a.nW, wx = wi - wy * a.nW;
+  const int g2 = a.grid * a.grid;
+  char* Kt = smem; char* Vt = smem + WIN_KV;
+  float* T = (float*)(smem + 2 * WIN_KV + wave * WIN_T);
+
+  // ---- 1. K / V of the window -> LDS (LDS-DMA: no registers, in flight during steps 2-4). 56 wave-instructions of 8 rows =
+  // half a window row each: instruction i covers key row kh = (i % 28) / 2 (wave-uniform) and columns kw = 8 (i & 1) + lane / 8,
+  // so the per-lane part of the address (column, chunk, image-border test in x) is computed once for the two column halves and
+  // the per-instruction part (row y, K or V plane) is scalar.
+  {
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+    const int sl = lane & 7;
+    long colp[2]; bool okx[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int kw = min(8 * hf + (lane >> 3), 13), x = wx * 14 + kw;
+      okx[hf] = x < a.grid;
+      colp[hf] = ((long)b * g2 + x) * a.d3 + head * 64;          // element offset of (row y = 0, column x) of this head's q slice
+    }
+#pragma unroll
+    for (int i8 = 0; i8 < 8; ++i8) {
+      const int i = wave * 8 + i8;                       // wave-uniform
+      const bool isv = i >= 28;
+      const int ii = isv ? i - 28 : i, kh = ii >> 1, hf = ii & 1, y = wy * 14 + kh;
+      // K: source chunk swizzled for conflict-free ds_read_b128 (LDS row R = 16 kh + 8 hf + lane / 8: (R >> 1) & 7 = 4 hf + lane / 16)
+      const int chunk = isv ? sl : (sl ^ (4 * hf + (lane >> 4)));
+      const long plane = (long)(isv ? 2 : 1) * a.H * 64 + chunk * 8;
+      const bf16_t* src = (y < a.grid && okx[hf]) ? a.q + colp[hf] + (long)y * a.grid * a.d3 + plane : a.pad_row + head * 64 + plane;
+      glds16(src, lds0 + (isv ? WIN_KV : 0) + ii * 1024);
+    }
+  }
+
+  // ---- 2. this lane's query (lanes r and r + 32 hold the same query: k halves of every 16-wide K-step)
+  const int tq = min(wave * 32 + r, 195);
+  const int qh = (tq * 4682) >> 16, qw = tq - 14 * qh;     // tq / 14 for tq < 224
+  uint4 qf[4];
+  {
+    const int y = wy * 14 + qh, x = wx * 14 + qw;
+    const bf16_t* qp = (y < a.grid && x < a.grid) ? a.q + ((long)b * g2 + (long)y * a.grid + x) * a.d3 + head * 64 : a.pad_row + head * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *(const uint4*)(qp + 16 * c + 8 * h);
+  }
+
+  // ---- 3. rel-pos tables from the UNSCALED q, log2 domain: T[j][q] = log2e * Rtable[j,:] . q. Column table first (gathered
+  // into 8 registers), then the row table, which stays in the wave's LDS region for the main loop.
+  float colb[8];
+#pragma unroll 1
+  for (int tbl = 0; tbl < 2; ++tbl) {
+    const float* table = tbl == 0 ? a.rel_w : a.rel_h;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int j = min(r, 26);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)), __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = acc_row(e, h);
+      if (row < 27) T[row * 32 + r] = acc[e] * a.tbl_scale;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // lanes exchange table entries through LDS (compiler-only fence)
+    if (tbl == 0) {
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        const int kw = (e8 & 3) + 8 * (e8 >> 2) + 4 * h;
+        colb[e8] = kw < 14 ? T[(qw - min(kw, 13) + 13) * 32 + r] : -INFINITY;      // kw = 14, 15: padding slots
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... before the row table overwrites the column table
+    }
+  }
+
+  // ---- 4. the score MFMA works directly in the log2 domain: q must carry scale * log2(e). The engine folds that factor into
+  // the q rows of the qkv weight at pack time (q_prescale: no run-time cost, ONE rounding of the scaled weight); a caller that
+  // passes raw q (scale_log2 != 1) gets it re-scaled here (bf16 -> bf16: one more rounding on the q side).
+  if (a.scale_log2 != 1.0f) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t w[4] = {qf[c].x, qf[c].y, qf[c].z, qf[c].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = pk2(__uint_as_float(w[i] << 16) * a.scale_log2, __uint_as_float(w[i] & 0xffff0000u) * a.scale_log2);
+      qf[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V pieces have landed
+  __syncthreads();                                      // ... and everybody else's
+
+  // ---- 5. main loop: 7 blocks of 32 keys (two window rows each), no barrier
+  const int sw = (r >> 1) & 7;
+  const int k_rd = r * 128, v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int t_rd = (qh + 13) * 32 + r;                  // row table index of key row kh: t_rd - 32 * kh
+  f32x16 o[2], lsum;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; lsum[e] = 0.f; }
+  float m = 0.f;
+  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
+#pragma unroll
+  for (int blk = 0; blk < 7; ++blk) {
+    const char* Kb = Kt + blk * 32 * 128 + k_rd;
+    uint4 kf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kf[c] = *(const uint4*)(Kb + (((2 * c + h) ^ sw) << 4));
+    const float rm0 = T[t_rd - 32 * (2 * blk)] - m, rm1 = T[t_rd - 32 * (2 * blk + 1)] - m;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = colb[e & 7] + (e < 8 ? rm0 : rm1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[c]), __builtin_bit_cast(bf16x8, qf[c]), s, 0, 0, 0);
+    float mloc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int e = 4; e < 16; e += 4) mloc = fmaxf(mloc, fmaxf(fmaxf(s[e], s[e + 1]), fmaxf(s[e + 2], s[e + 3])));
+    mloc = fmaxf(mloc, other_half(mloc));               // block maximum of x - m for this query
+    // reference update: always after the first block (m = its maximum), later only when a block maximum exceeds it by 2^8
+    if (blk == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
+      const float d = blk == 0 ? mloc : fmaxf(mloc, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-d);
+      m += d;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] -= d;
+      if (blk != 0) {
+        lsum[0] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+      }
+    }
+    uint4 pf[2];
+    {
+      f32x16 p;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[e]);
+      pf[0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+      pf[1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const char* vb = Vt + (blk * 32 + ks * 16) * 128 + db * 64 + v_tr;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
+        const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+        const uint4 vfr = make_uint4(u0.x, u0.y, u1.x, u1.y);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr), __builtin_bit_cast(bf16x8, pf[ks]), o[db], 0, 0, 0);
+      }
+      lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[ks]), lsum, 0, 0, 0);
+    }
+  }
+
+  // ---- 6. O / l, transposed through the wave's own LDS region (the row table is dead), one 32-column half (bf16) or 16-column
+  // quarter (fp32) of the 32 query rows at a time (row stride 80 B, 2560 B), stored as 64-byte row pieces, 16 rows per instruction.
+  // EVERY lane writes before any lane reads and wavefront-scope fences separate the two: lanes exchange data through LDS here,
+  // which single-thread reasoning does not see (a conditional write followed by a read let hipcc forward a stale register).
+  const float inv = 1.0f / lsum[0];
+  char* stg = (char*)T;
+  TO* out = (TO*)a.o;
+  auto off = [&](int jq) -> long {
+    const int tj = wave * 32 + jq;
+    if (tj >= 196) return -1;
+    const int jh = (tj * 4682) >> 16, y = wy * 14 + jh, x = wx * 14 + (tj - 14 * jh);
+    if (y >= a.grid || x >= a.grid) return -1;
+    return ((long)b * g2 + (long)y * a.grid + x) * (long)(a.H * 64) + head * 64;
+  };
+  const long e0 = off(lane >> 2), e1 = off((lane >> 2) + 16);
+  const int rd0 = (lane >> 2) * 80 + (lane & 3) * 16;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 u;
+        u.x = pk2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv); u.y = pk2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        *(uint2*)(stg + r * 80 + (8 * g + 4 * h) * 2) = u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint4 v0 = *(const uint4*)(stg + rd0), v1 = *(const uint4*)(stg + rd0 + 16 * 80);
+      if (e0 >= 0) *(uint4*)(out + e0 + db * 32 + (lane & 3) * 8) = v0;
+      if (e1 >= 0) *(uint4*)(out + e1 + db * 32 + (lane & 3) * 8) = v1;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  } else {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {                    // columns 16 qd .. 16 qd + 15: accumulator half db = qd >> 1, registers 8 (qd & 1) ..
+      const int db = qd >> 1, g0 = 2 * (qd & 1);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = g0 + gg;
+        const f32x4 v4 = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+        *(f32x4*)(stg + r * 80 + (8 * gg + 4 * h) * 4) = v4;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const f32x4 v0 = *(const f32x4*)(stg + rd0), v1 = *(const f32x4*)(stg + rd0 + 16 * 80);
+      if (e0 >= 0) *(f32x4*)(out + e0 + qd * 16 + (lane & 3) * 4) = v0;
+      if (e1 >= 0) *(f32x4*)(out + e1 + qd * 16 + (lane & 3) * 4) = v1;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+}
+
+template <typename TO>
+int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)win_attn<TO>, WIN_LDS, once);
+  hipLaunchKernelGGL((win_attn<TO>), dim3(nwin * a.H), dim3(448), WIN_LDS, s, a);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename TO>
 int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
@@ -701,8 +937,9 @@ int launch(const FlashArgs& a, int nb, hipStream_t s) {
 
 }  // namespace
 
-// `variant` (per call): 0 (default) = flash_global_pipe, software-pipelined over key tiles; 1 = flash_fwd<1>, the unpipelined
-// chain form (kept as the in-process A/B and parity partner: tests/test_gpu_parity.py, tools/attn_bench.py).
+// `variant` (per call): 0 (default) = flash_global_pipe (global; software-pipelined over key tiles) / win_attn (windowed; one
+// 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>, the round-1 chain forms of the same arithmetic (kept as
+// the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -712,17 +949,19 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
   FlashArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = out;
   a.q_sb = q_sb; a.q_st = q_st; a.k_sb = k_sb; a.k_st = k_st; a.v_sb = v_sb; a.v_st = v_st; a.o_sb = o_sb; a.o_st = o_st;
-  a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale_log2 = scale * LOG2E; a.S = 1; a.grid = 1; a.nW = 1;
+  a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale_log2 = scale * LOG2E; a.tbl_scale = LOG2E; a.S = 1; a.grid = 1; a.nW = 1;
   if (out_dtype == COR_BF16) return launch<0, bf16_t>(a, B, s);
   if (out_dtype == COR_F32) return launch<0, float>(a, B, s);
   return COR_ENOSUPPORT;
 }
 
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w, int B,
-                       int H, int grid, int window, int variant, hipStream_t s) {
+                       int H, int grid, int window, float q_prescale, int variant, hipStream_t s) {
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
-  a.q = (const bf16_t*)qkv; a.o = out; a.H = H; a.scale_log2 = 0.125f * LOG2E;
+  a.q = (const bf16_t*)qkv; a.o = out; a.H = H;
+  a.scale_log2 = 0.125f * LOG2E / q_prescale; a.tbl_scale = LOG2E / q_prescale;
+  if (fabsf(a.scale_log2 - 1.0f) < 1e-6f) { a.scale_log2 = 1.0f; a.tbl_scale = 8.0f; }   // q_prescale = 0.125 * log2(e): exact constants
   a.pad_row = (const bf16_t*)pad_row; a.rel_h = rel_h; a.rel_w = rel_w; a.grid = grid; a.d3 = 3 * H * 64;
   if (window == 0) {
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
@@ -737,6 +976,11 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   }
   if (window != 14 || ((uintptr_t)pad_row & 15)) return COR_ENOSUPPORT;
   a.S = 14; a.Tq = a.Tk = 196; a.nW = (grid + 13) / 14;
+  if (variant == 0) {                                   // one 7-wave block per (window, head)
+    if (out_dtype == COR_BF16) return launch_win<bf16_t>(a, B * a.nW * a.nW, s);
+    if (out_dtype == COR_F32) return launch_win<float>(a, B * a.nW * a.nW, s);
+    return COR_ENOSUPPORT;
+  }
   if (out_dtype == COR_BF16) return launch<2, bf16_t>(a, B * a.nW * a.nW, s);
   if (out_dtype == COR_F32) return launch<2, float>(a, B * a.nW * a.nW, s);
   return COR_ENOSUPPORT;

@@ -311,31 +311,44 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 constexpr float SIM_DELTA = 6.4e-5f * 1.01f;
 constexpr int FS_MAX = 8192;                           // candidates per query held in LDS by sim_final (64 KiB)
 constexpr int SL_MAX = 512;                            // short list (re-scored exactly)
-constexpr int SCAN_NS = 8, SCAN_AHEAD = 7;             // LDS-DMA ring of 16-KiB gallery tiles: 128 KiB, one block per CU
+constexpr int SCAN_NS = 4, SCAN_AHEAD = 3;             // LDS-DMA ring of 32-KiB gallery super-tiles (64 rows): 128 KiB, one block per CU
 
 struct ScanArgs {
   int Bq, Ng, nqg, nsplit, tiles_per_split;
-  int ntiles;                      // tiles this launch walks (SAMPLE: sample tiles; APPEND: all tiles)
-  int tile_stride;                 // gallery tiles between consecutive walked tiles (SAMPLE: >= 1; APPEND: 1)
+  int ntiles;                      // 64-row super-tiles this launch walks (SAMPLE: sample super-tiles; APPEND: all of them)
+  int tile_stride;                 // super-tiles between consecutive walked super-tiles (SAMPLE: >= 1; APPEND: 1)
+  const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep)
   float* pmax; int ngroups;        // SAMPLE: pmax[q * ngroups + split * 2 + h]
-  const float* tau; int* cnt; float* cand_s; int* cand_i; int cap;   // APPEND
+  float tau_add;                   // 0; timing-only ablation (COR_TOPK_DEBUG_NOCAND): +1e30 = no candidate ever passes
+  const float* tau; int* cnt; float* rec_s; int* rec_g; int cap;     // APPEND: record i of stream (q, slice, half): 16 scores + first row
 };
 
 // One block = 8 waves = 256 * QB queries (wave w owns queries q0 + 32 * QB * w ..): with QB = 2 all 512 queries of an
 // 8-GPU all-gather (8 x 64) sit in ONE block, so every gallery byte is fetched from HBM once per launch (512 MB at 1M rows)
 // and the kernel is MFMA-bound (arithmetic intensity = queries per block FLOP/B against a ridge of ~400); the K-fragments of
 // the wave's queries stay in registers for the whole kernel (QB * 64 VGPRs) and each A fragment read from LDS feeds QB MFMAs.
-// Gallery tiles (32 rows x 512 B) stream through an 8-slot LDS-DMA ring, 7 tiles (112 KiB per CU) in flight: counted
-// s_waitcnt vmcnt, one barrier per tile. The LDS image is lane-linear per wave-instruction (64 lanes x 16 B = two 512-B
+// Gallery super-tiles (64 rows x 512 B = two MFMA tiles) stream through a 4-slot LDS-DMA ring, 3 of them (96 KiB per CU) in
+// flight: counted s_waitcnt vmcnt, ONE barrier per 64 rows. The LDS image is lane-linear per wave-instruction (64 lanes x 16 B = two 512-B
 // rows), so slot (row, sl) is fed from source chunk sl ^ (row & 15) and the reads apply the same XOR (conflict-free b128).
+// max of three. NOT inline asm: hipcc pads no MFMA -> VALU read hazard for an asm statement, so a v_max3_f32 in asm read the
+// accumulators before the matrix pipe had written them (sporadic missed candidates). The file is built with -fno-honor-nans
+// (Makefile) so that fmaxf needs no canonicalising v_max x,x,x per operand and folds to v_max3_f32 by itself.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 template <typename TG, int QB, bool SAMPLE>
-__global__ void __launch_bounds__(512, 2) sim_scan(const float* __restrict__ Q, const TG* __restrict__ G, const ScanArgs a) {
+__global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int C = 256, TILE = 32 * C * 2, NS = SCAN_NS, AHEAD = SCAN_AHEAD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  constexpr int C = 256, TILE = 32 * C * 2, STILE = 2 * TILE, NS = SCAN_NS, AHEAD = SCAN_AHEAD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int qg = blockIdx.x % a.nqg, split = blockIdx.x / a.nqg;
   const int q0 = qg * (256 * QB) + wave * (32 * QB);
   const bool active = q0 < a.Bq;                     // wave-uniform: idle waves still stage and barrier
+  // Waves w and w + 4 share a SIMD and, running the same program between the same barriers, would reach their MFMAs, their
+  // VALU epilogues and the barrier TOGETHER: the matrix pipe then idles through every epilogue. The younger half (waves 4-7)
+  // therefore runs the epilogue of a tile AFTER the next barrier, in front of its next MFMAs, i.e. beside the MFMAs of its
+  // SIMD partner (MI355X guide, "two waves per SIMD", item 9); the accumulators are not overwritten until then, so no
+  // double buffering is needed.
+  const bool late = wave >= 4;
 
   uint4 qf[QB][16];
   float tau[QB], gmax[QB];
@@ -343,103 +356,120 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const float* __restrict__ Q, 
   const int nstreams = a.nsplit * 2;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const int q = min(q0 + qb * 32 + r, a.Bq - 1);
-    const float* qrow = Q + (long)q * C;
+    // K-fragments from the fragment-major image sim_prep wrote (query block, K-step, lane) x 16 B: 1 KiB per wave-instruction,
+    // 16 of them per query block (reading the fp32 rows cost every CU 512 KiB of L2 traffic per launch: ~7 us)
+    const uint4* qimg = a.qimg + ((long)(q0 / 32 + qb) * 16) * 64 + lane;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) qf[qb][c] = q_frag16<TG>(qrow, c, h);
-    tau[qb] = SAMPLE ? 0.f : a.tau[q];
+    for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
+    const int q = min(q0 + qb * 32 + r, a.Bq - 1);
+    tau[qb] = SAMPLE ? 0.f : a.tau[q] + a.tau_add;
     gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
-  const unsigned wbase = __builtin_amdgcn_readfirstlane(tid & ~63) * 16;       // this wave's first slot (bytes) per 8-KiB pass
-  int st_row[2], st_src[2];
+  const unsigned wbase = (unsigned)wave * 1024u;       // this wave's first slot (bytes) per 8-KiB pass
+  int st_row[4], st_src[4];                            // a super-tile = 64 rows x 512 B = four 8-KiB passes of the block
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int c = tid + 512 * i, row = c >> 5, sl = c & 31;
     st_row[i] = row; st_src[i] = (sl ^ (row & 15)) * 8;
   }
   // read address of K-step c: row r, chunk (2c + h) ^ (r & 15) = ((c ^ (r>>1 & 7)) << 1) | ((h ^ r) & 1): one XOR per read instead
-  // of 16 address registers (the APPEND form otherwise spills, and a spill reload drains the LDS-DMA ring: vmcnt(0))
+  // of 16 address registers
   const int rd_base = r * 512 + (((h ^ r) & 1) << 4), rd_x = (r >> 1) & 7;
 #define SIM_RD(c_) (rd_base + ((((c_) ^ rd_x)) << 5))
 
-  const int t0 = split * a.tiles_per_split, t1 = min(t0 + a.tiles_per_split, a.ntiles);
+  const int t0 = split * a.tiles_per_split, t1 = min(t0 + a.tiles_per_split, a.ntiles);     // super-tiles of 64 rows
   auto issue = [&](int t) {
-    const long g0 = (long)t * a.tile_stride * 32;
-    const unsigned dst = lds0 + ((t - t0) % NS) * TILE + wbase;
+    const long g0 = (long)t * a.tile_stride * 64;
+    const unsigned dst = lds0 + ((t - t0) % NS) * STILE + wbase;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
       glds16(G + min(g0 + st_row[i], (long)a.Ng - 1) * C + st_src[i], dst + 512 * 16 * i);
   };
-  for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
-  for (int t = t0; t < t1; ++t) {
-    // tile t has landed once at most 2 * (tiles issued after t) of this wave's DMA are still outstanding (VMEM retires in
-    // order; candidate stores issued in between only make the wait stricter)
-    const int later = min(t1 - 1 - t, AHEAD - 1);
-    switch (later) {
-      case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-    __builtin_amdgcn_s_barrier();                      // every wave's part of tile t is in LDS; tile t-1 is fully consumed
-    if (t + AHEAD < t1) issue(t + AHEAD);              // -> ring slot of tile t-1
-    const char* buf = smem + ((t - t0) % NS) * TILE;
-    if (active) {
-      f32x16 acc[QB];
+  f32x16 acc[QB];
+  // epilogue of one 32-row tile (rows g0 ..): SAMPLE keeps the group maximum; APPEND compares the tile maximum with tau and
+  // appends the rare scores >= tau to the lane's private stream list
+  const int h4 = 4 * h;
+  auto epilogue = [&](int g0) {
+    const int lim = a.Ng - g0;                         // rows of this tile inside the shard (scalar); < 32 only at the shard's end
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
+    for (int qb = 0; qb < QB; ++qb) {
+      if (lim < 32) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[qb][e] = 0.f;
-      // A fragments four K-steps ahead of the MFMAs that consume them
-      uint4 af[4];
+        for (int e = 0; e < 16; ++e)
+          if (h4 + ((e & 3) + 8 * (e >> 2)) >= lim) acc[qb][e] = -INFINITY;          // clamped duplicate rows never count
+      }
+      float tmax = max3f(acc[qb][0], acc[qb][1], acc[qb][2]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + SIM_RD(c));
+      for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, acc[qb][e], acc[qb][e + 1]);
+      tmax = fmaxf(tmax, acc[qb][15]);
+      if (SAMPLE) {
+        gmax[qb] = fmaxf(gmax[qb], tmax);
+      } else if (__builtin_amdgcn_ballot_w64(tmax >= tau[qb]) != 0) {
+        // Some lane of the wave has a candidate in this tile (about every third tile and query block at 512 x 1M). Testing
+        // the 16 registers one by one cost ~80 instructions per triggered tile (70 us of a 270-us scan); instead a lane
+        // whose tile maximum passes appends its WHOLE 16-score column as one record (4 x 16-byte stores + the tile's first
+        // row) to its private stream list, and sim_final filters the records against tau: ~20 instructions, no inner branch.
+        int q = q0 + qb * 32 + r;
+        asm volatile("" : "+v"(q));                    // opaque: keeps the list address arithmetic HERE (hoisted out of the tile loop
+        if (tmax >= tau[qb] && q < a.Bq) {             // it was spilled, and a spill reload inside the loop drains the DMA ring)
+          if (ncand[qb] < a.cap) {
+            const long rec = ((long)q * nstreams + split * 2 + h) * a.cap + ncand[qb];
+            f32x4* dst = (f32x4*)(a.rec_s + rec * 16);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const uint4 av = af[c & 3];
-        if (c + 4 < 16) af[c & 3] = *(const uint4*)(buf + SIM_RD(c + 4));
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          if (__is_same(TG, bf16_t))
-            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][c]), acc[qb], 0, 0, 0);
-          else
-            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][c]), acc[qb], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) dst[g] = f32x4{acc[qb][4 * g], acc[qb][4 * g + 1], acc[qb][4 * g + 2], acc[qb][4 * g + 3]};
+            a.rec_g[rec] = g0;
+          }
+          ++ncand[qb];
         }
       }
-      const long g0 = (long)t * a.tile_stride * 32;
-      const bool ragged = g0 + 32 > a.Ng;              // wave-uniform: only the shard's last tile
+    }
+  };
+  auto mfma_tile = [&](const char* buf) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[qb][e] = 0.f;
+    uint4 af[4];                                       // A fragments four K-steps ahead of the MFMAs that consume them
+#pragma unroll
+    for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + SIM_RD(c));
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const uint4 av = af[c & 3];
+      if (c + 4 < 16) af[c & 3] = *(const uint4*)(buf + SIM_RD(c + 4));
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        if (ragged) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (g0 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.Ng) acc[qb][e] = -INFINITY;   // clamped duplicate rows never count
-        }
-        float tmax = fmaxf(fmaxf(acc[qb][0], acc[qb][1]), fmaxf(acc[qb][2], acc[qb][3]));
-#pragma unroll
-        for (int e = 4; e < 16; e += 4) tmax = fmaxf(tmax, fmaxf(fmaxf(acc[qb][e], acc[qb][e + 1]), fmaxf(acc[qb][e + 2], acc[qb][e + 3])));
-        if (SAMPLE) {
-          gmax[qb] = fmaxf(gmax[qb], tmax);
-        } else if (__builtin_amdgcn_ballot_w64(tmax >= tau[qb]) != 0) {          // rare after the sample threshold
-          const int q = q0 + qb * 32 + r;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            if (acc[qb][e] >= tau[qb] && acc[qb][e] > -INFINITY && q < a.Bq) {     // (-inf = masked row beyond the shard; tau may be -inf)
-              if (ncand[qb] < a.cap) {
-                const long o = ((long)q * nstreams + split * 2 + h) * a.cap + ncand[qb];
-                a.cand_s[o] = acc[qb][e]; a.cand_i[o] = (int)g0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              }
-              ++ncand[qb];
-            }
-          }
-        }
+        if (__is_same(TG, bf16_t))
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][c]), acc[qb], 0, 0, 0);
+        else
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][c]), acc[qb], 0, 0, 0);
       }
     }
+  };
+
+  for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
+  int g_pending = -1;                                  // late waves: tile whose epilogue is still owed
+  for (int t = t0; t < t1; ++t) {
+    // super-tile t has landed once at most 4 * (super-tiles issued after t) of this wave's DMA are still outstanding (VMEM
+    // retires in order; candidate stores issued in between only make the wait stricter)
+    const int later = min(t1 - 1 - t, AHEAD - 1);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave's part of super-tile t is in LDS; t-1 is fully consumed
+    if (t + AHEAD < t1) issue(t + AHEAD);              // -> ring slot of super-tile t-1
+    const char* buf = smem + ((t - t0) % NS) * STILE;
+    const int g0 = t * a.tile_stride * 64;
+    if (active) {
+      if (late && g_pending >= 0) epilogue(g_pending);
+      mfma_tile(buf);
+      epilogue(g0);
+      mfma_tile(buf + TILE);
+      if (late) g_pending = g0 + 32; else epilogue(g0 + 32);
+    }
   }
+  if (active && late && g_pending >= 0) epilogue(g_pending);
+#undef SIM_RD
   if (active) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -452,7 +482,21 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const float* __restrict__ Q, 
   }
 }
 
-#undef SIM_RD
+// Queries rounded to the gallery dtype in MFMA-fragment order: image[(qblk * 16 + c) * 64 + lane] = 16 B = q[qblk*32 + (lane&31)]
+// [16c + 8(lane>>5) .. +8]; rows beyond Bq repeat the last query (their results are never written). Also clears the per-call
+// overflow flags. One block of 256 threads per 32 queries.
+template <typename TG>
+__global__ void __launch_bounds__(256) sim_prep(const float* __restrict__ Q, int Bq, uint4* img, int* flags, int* ovf_q) {
+  const int qblk = blockIdx.x, tid = threadIdx.x;
+  if (qblk == 0 && tid == 0) flags[0] = 0;
+  if (tid < 32 && qblk * 32 + tid < Bq) ovf_q[qblk * 32 + tid] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int item = tid + 256 * i, c = item >> 6, lane = item & 63, r = lane & 31, h = lane >> 5;
+    const float* qrow = Q + (long)min(qblk * 32 + r, Bq - 1) * 256;
+    img[((long)qblk * 16 + c) * 64 + lane] = q_frag16<TG>(qrow, c, h);
+  }
+}
 
 template <typename TG> __device__ __forceinline__ float round_to(float x);
 template <> __device__ __forceinline__ float round_to<bf16_t>(float x) { return bf2f(f2bf(x)); }
@@ -462,11 +506,9 @@ template <> __device__ __forceinline__ float round_to<_Float16>(float x) { retur
 // ngroups < k (or no sample at all: ngroups == 0) gives -inf: every row is then a candidate.
 template <typename TG>
 __global__ void __launch_bounds__(256) sim_tau(const float* __restrict__ Q, const float* __restrict__ pmax, int ngroups, int Bq, int k,
-                                               float* tau, int* flags, int* ovf_q) {
+                                               float* tau) {
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0;          // per-call overflow flag (read by the gated fallback kernels)
   if (q >= Bq) return;
-  if (lane == 0) ovf_q[q] = 0;
   float nrm = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const float v = round_to<TG>(Q[(long)q * 256 + lane * 4 + i]); nrm = fmaf(v, v, nrm); }
@@ -495,11 +537,77 @@ __global__ void __launch_bounds__(256) sim_tau(const float* __restrict__ Q, cons
 
 __device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
+// chain score of gallery row `idx` against the query in LDS (oracle/c/sim_chain.c order: chunk c of 8: k = 8c+i then 8c+4+i)
+template <typename TG>
+__device__ __forceinline__ float chain_score(const TG* __restrict__ G, long idx, const float* qs) {
+  const uint4* row = (const uint4*)(G + idx * 256);
+  float acc = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < 32; ++c) {
+    const uint4 v = row[c];
+    float g[8];
+    if (__is_same(TG, bf16_t)) {
+      g[0] = __uint_as_float(v.x << 16); g[1] = __uint_as_float(v.x & 0xffff0000u); g[2] = __uint_as_float(v.y << 16); g[3] = __uint_as_float(v.y & 0xffff0000u);
+      g[4] = __uint_as_float(v.z << 16); g[5] = __uint_as_float(v.z & 0xffff0000u); g[6] = __uint_as_float(v.w << 16); g[7] = __uint_as_float(v.w & 0xffff0000u);
+    } else {
+      const f16x8 hv = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = (float)hv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = fmaf(g[i], qs[8 * c + i], acc);
+      acc = fmaf(g[4 + i], qs[8 * c + 4 + i], acc);
+    }
+  }
+  return acc;
+}
+
+// Exact fallback of ONE query (block of 256 threads): every row's chain score, per-thread sorted top-k lists in LDS (thread t
+// owns slots [t*k, t*k + k) of cs/ci: 256 * k <= FS_MAX), then k rounds of block-wide arg-best by (score desc, index asc).
+template <typename TG>
+__device__ void brute_force_topk(const TG* __restrict__ G, int Ng, const float* qs, float* cs, int* ci, int k, long long g_offset,
+                                 float* out_s, long long* out_i) {
+  __shared__ float rs[4]; __shared__ int ri[4], rp[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = tid * k;
+  for (int j = 0; j < k; ++j) { cs[base + j] = -INFINITY; ci[base + j] = INT_MAX; }
+  for (int g = tid; g < Ng; g += 256) {                  // ascending rows: a tie keeps the earlier (smaller) index ahead
+    const float sc = chain_score<TG>(G, g, qs);
+    if (sc > cs[base + k - 1]) {
+      int j = k - 1;
+      while (j > 0 && sc > cs[base + j - 1]) { cs[base + j] = cs[base + j - 1]; ci[base + j] = ci[base + j - 1]; --j; }
+      cs[base + j] = sc; ci[base + j] = g;
+    }
+  }
+  __syncthreads();
+  const int n = 256 * k;
+  for (int round = 0; round < k; ++round) {
+    float bs = -INFINITY; int bi = INT_MAX, bp = -1;
+    for (int i = tid; i < n; i += 256)
+      if (ci[i] != INT_MAX && (bp < 0 || cs[i] > bs || (cs[i] == bs && ci[i] < bi))) { bs = cs[i]; bi = ci[i]; bp = i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, 64); const int oi = __shfl_xor(bi, o, 64), op = __shfl_xor(bp, o, 64);
+      if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+    }
+    if (lane == 0) { rs[wave] = bs; ri[wave] = bi; rp[wave] = bp; }
+    __syncthreads();
+    if (tid == 0) {
+      float fs = rs[0]; int fi = ri[0], fp = rp[0];
+      for (int w = 1; w < 4; ++w) if (rp[w] >= 0 && (fp < 0 || rs[w] > fs || (rs[w] == fs && ri[w] < fi))) { fs = rs[w]; fi = ri[w]; fp = rp[w]; }
+      out_s[round] = fp >= 0 ? fs : -INFINITY;
+      out_i[round] = fp >= 0 ? (long long)fi + g_offset : -1LL;
+      if (fp >= 0) ci[fp] = INT_MAX;
+    }
+    __syncthreads();
+  }
+}
+
 // D. exact top-k of one query's candidates. LDS: cs/ci [FS_MAX] | sl_s/sl_i [SL_MAX] | qs[256] | hist[256].
 template <typename TG>
-__global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, const TG* __restrict__ G, const float* cand_s, const int* cand_i,
-                                                 const int* cnt, int nstreams, int cap, int k, long long g_offset, float* out_s,
-                                                 long long* out_i, int* flags, int* ovf_q, int no_fallback) {
+__global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, const TG* __restrict__ G, const float* rec_s, const int* rec_g,
+                                                 const float* tau, const int* cnt, int nstreams, int cap, int Ng, int k, long long g_offset,
+                                                 float* out_s, long long* out_i, int* flags, int* ovf_q, int no_fallback) {
   extern __shared__ __attribute__((aligned(16))) char fsraw[];
   float* cs = (float*)fsraw; int* ci = (int*)(cs + FS_MAX);
   float* sl_s = (float*)(ci + FS_MAX); int* sl_i = (int*)(sl_s + SL_MAX);
@@ -514,28 +622,46 @@ __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, co
   if (lane == 0) qn2[wave] = part;
   __syncthreads();
   const float delta = SIM_DELTA * fmaxf(1.f, sqrtf(qn2[0] + qn2[1] + qn2[2] + qn2[3]));
-  // 1. compaction of the private stream lists
+  // 1. the private stream lists hold whole 16-score columns (records): keep the scores >= tau_q (the admission threshold of
+  // the scan, delta already subtracted) and compact them into LDS. Register e of lane half h is row g0 + (e&3) + 8 (e>>2) + 4 h.
+  const float tq = tau[q];
+  auto take = [&](const f32x4 (&v)[4], int g0, int h4) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (v[g][i] >= tq && v[g][i] > -INFINITY) {
+          const int p = atomicAdd(&total, 1);
+          if (p < FS_MAX) { cs[p] = v[g][i]; ci[p] = g0 + i + 8 * g + h4; }
+        }
+  };
   for (int st = tid; st < nstreams; st += 256) {
+    // record 0 of every stream is fetched TOGETHER with the stream's count (most streams hold 0 or 1 records): one global
+    // round trip instead of three dependent ones; its contents are ignored when the count is 0
+    const long rec0 = ((long)q * nstreams + st) * cap;
+    const f32x4* src = (const f32x4*)(rec_s + rec0 * 16);
+    const f32x4 v0[4] = {src[0], src[1], src[2], src[3]};
+    const int g00 = rec_g[rec0];
     const int c = cnt[(long)q * nstreams + st];
     if (c > cap) ovf = 1;
-    const int n = min(c, cap);
-    if (n > 0) {
-      const int base = atomicAdd(&total, n);
-      const long src = ((long)q * nstreams + st) * cap;
-      for (int j = 0; j < n; ++j)
-        if (base + j < FS_MAX) { cs[base + j] = cand_s[src + j]; ci[base + j] = cand_i[src + j]; }
+    const int n = min(c, cap), h4 = 4 * (st & 1);
+    if (n > 0) take(v0, g00, h4);
+    for (int j = 1; j < n; ++j) {
+      const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 16);
+      const f32x4 vj[4] = {sj[0], sj[1], sj[2], sj[3]};
+      take(vj, rec_g[rec0 + j], h4);
     }
   }
   __syncthreads();
   if (total > FS_MAX) ovf = 1;
   const int n = min(total, FS_MAX);
   __syncthreads();
-  // 2. T = k-th best MFMA score (4-pass radix select over order-preserving keys); n <= k: every candidate is in
+  // 2. T_lo <= T = k-th best MFMA score (2-pass radix select over order-preserving keys); n <= k: every candidate is in
   float T = -INFINITY;
   if (!ovf && n > k) {
     unsigned prefix = 0;
     if (tid == 0) k_rem = k;
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {               // 16 key bits: sign, exponent, 7 mantissa bits
       const int shift = 24 - 8 * pass;
       hist[tid] = 0;
       __syncthreads();
@@ -562,7 +688,10 @@ __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, co
       prefix = (prefix << 8) | (unsigned)sel_bin;
       __syncthreads();
     }
-    const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    // T_lo = the smallest float whose key starts with the k-th best score's 16 bits: T_lo <= T (within 2^-7 relative), so the
+    // short list cut T_lo - delta admits a superset of what T - delta would (exactness is unaffected; two passes saved)
+    const unsigned key_lo = prefix << 16;
+    const unsigned u = (key_lo & 0x80000000u) ? (key_lo & 0x7fffffffu) : ~key_lo;
     T = __uint_as_float(u);
   }
   // 3. short list: MFMA score >= T - delta
@@ -578,37 +707,22 @@ __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, co
   __syncthreads();
   if (nsl > SL_MAX) ovf = 1;
   __syncthreads();
-  if (ovf) {                                             // flag the query; the gated list kernels behind recompute it
+  if (ovf) {
+    // Candidate overflow (a stream list, the LDS buffer or the short list: pathological score distributions such as tens of
+    // thousands of identical rows). No host round trip and no second launch: THIS block ranks the whole shard for its query
+    // with the exact chain (256 threads x Ng / 256 rows x 256 dependent fmaf: ~2 ms per query at 1M rows - slow, exact, rare).
     if (tid == 0) { ovf_q[q] = 1; atomicOr(flags, 1); }
-    for (int j = tid; j < k; j += 256) { out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -2LL; }
-    (void)no_fallback;
+    if (no_fallback) {                                   // tests: expose the raw overflow marker
+      for (int j = tid; j < k; j += 256) { out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -2LL; }
+      return;
+    }
+    __syncthreads();
+    brute_force_topk<TG>(G, Ng, qs, cs, ci, k, g_offset, out_s + (long)q * k, out_i + (long)q * k);
     return;
   }
   const int m = nsl;
   // 4. exact re-scoring: the fmaf chain of oracle/c/sim_chain.c (chunk c = 0..31 of 8: k = 8c+i then 8c+4+i, i = 0..3)
-  for (int j = tid; j < m; j += 256) {
-    const uint4* row = (const uint4*)(G + (long)sl_i[j] * 256);
-    float acc = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < 32; ++c) {
-      const uint4 v = row[c];
-      float g[8];
-      if (__is_same(TG, bf16_t)) {
-        g[0] = __uint_as_float(v.x << 16); g[1] = __uint_as_float(v.x & 0xffff0000u); g[2] = __uint_as_float(v.y << 16); g[3] = __uint_as_float(v.y & 0xffff0000u);
-        g[4] = __uint_as_float(v.z << 16); g[5] = __uint_as_float(v.z & 0xffff0000u); g[6] = __uint_as_float(v.w << 16); g[7] = __uint_as_float(v.w & 0xffff0000u);
-      } else {
-        const f16x8 hv = __builtin_bit_cast(f16x8, v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = (float)hv[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc = fmaf(g[i], qs[8 * c + i], acc);
-        acc = fmaf(g[4 + i], qs[8 * c + 4 + i], acc);
-      }
-    }
-    sl_s[j] = acc;
-  }
+  for (int j = tid; j < m; j += 256) sl_s[j] = chain_score<TG>(G, sl_i[j], qs);
   __syncthreads();
   // 5. rank by (chain score desc, index asc); entries beyond the short list (Ng < k) are (-inf, -1)
   for (int j = tid; j < m; j += 256) {
@@ -662,13 +776,13 @@ struct V3Plan {
   int qb, nqg;                       // query blocks per wave (1 | 2), query groups of 256 * qb
   int tiles, nsplit, tiles_per_split, nstreams, cap;                 // APPEND pass
   int s_stride, s_tiles, s_nsplit, s_tiles_per_split, ngroups;       // SAMPLE pass (ngroups == 0: no sample, tau = -inf)
-  size_t off_pmax, off_tau, off_flags, off_ovf, off_cnt, off_cs, off_ci, off_lists, bytes;
+  size_t off_img, off_pmax, off_tau, off_flags, off_ovf, off_cnt, off_recs, off_recg, off_lists, bytes;
 };
 inline V3Plan make_v3(int Bq, int Ng, int k) {
   V3Plan p{};
   p.qb = Bq > 256 ? 2 : 1;
   p.nqg = cdiv(Bq, 256 * p.qb);
-  p.tiles = cdiv(Ng, 32);
+  p.tiles = cdiv(Ng, 64);                              // 64-row super-tiles
   int want = device_cus() / p.nqg;                     // one resident block per CU
   if (want > 256) want = 256;                          // nstreams <= 512 (sim_tau holds 8 group maxima per lane)
   if (want > p.tiles) want = p.tiles;
@@ -679,9 +793,11 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
   long expect;                                         // expected accepted scores per query over the whole shard
   if (Ng <= 4096) {                                    // tiny shard: no sample pass, every row is a candidate (<= FS_MAX)
     p.ngroups = 0; p.s_tiles = 0; p.s_stride = 1; p.s_nsplit = 0; p.s_tiles_per_split = 0;
-    p.cap = 16 * p.tiles_per_split;
+    p.cap = 2 * p.tiles_per_split;                     // records (32-row tiles) per (slice, lane half) stream: every tile is one
   } else {
-    p.s_stride = p.tiles / 16 >= 128 ? 16 : (p.tiles / 128 > 1 ? p.tiles / 128 : 1);   // every 16th tile, at least ~128 sample tiles
+    // every 16th super-tile, at least ~128 of them: the sample pass costs 1/stride of the full scan plus a fixed ~8 us; the
+    // candidates it admits (~2 k stride per query) must stay rare per wave and tile (the append path is divergent)
+    p.s_stride = p.tiles / 16 >= 128 ? 16 : (p.tiles / 128 > 1 ? p.tiles / 128 : 1);
     p.s_tiles = cdiv(p.tiles, p.s_stride);
     int sw = device_cus() / p.nqg;
     if (sw > 256) sw = 256;
@@ -691,18 +807,20 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
     p.s_nsplit = cdiv(p.s_tiles, p.s_tiles_per_split);
     p.ngroups = 2 * p.s_nsplit;
     expect = 3L * k * p.s_stride;                      // ~ k * Ng / sample rows, x3 for group-maximum slack
-    p.cap = (int)(4 * expect / p.nstreams) + 24;
+    // records per stream: Poisson with mean ~ expect / nstreams (< 1 on large shards); +10 keeps P(overflow) per search < 1e-4
+    p.cap = (int)(2 * expect / p.nstreams) + 10;
   }
   const TopkPlan2 p2 = make_plan2(Bq, Ng, k, device_cus());
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
+  p.off_img = take((size_t)p.nqg * 8 * p.qb * 16 * 64 * 16);        // whole query blocks of every group (rows past Bq: copies)
   p.off_pmax = take((size_t)Bq * (p.ngroups > 0 ? p.ngroups : 1) * 4);
   p.off_tau = take((size_t)Bq * 4);
   p.off_flags = take(16);
   p.off_ovf = take((size_t)Bq * 4);
   p.off_cnt = take((size_t)Bq * p.nstreams * 4);
-  p.off_cs = take((size_t)Bq * p.nstreams * p.cap * 4);
-  p.off_ci = take((size_t)Bq * p.nstreams * p.cap * 4);
+  p.off_recs = take((size_t)Bq * p.nstreams * p.cap * 64);
+  p.off_recg = take((size_t)Bq * p.nstreams * p.cap * 4);
   p.off_lists = take((size_t)Bq * p2.nparts * p2.kmax * 8);          // fallback list kernels
   p.bytes = o;
   return p;
@@ -734,7 +852,7 @@ int launch_lists_v2(const float* Q, const TG* G, int Bq, int Ng, int k, long lon
 template <typename TG, int QB>
 int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_offset, float* out_s, long long* out_i, char* w,
               const V3Plan& p, int flags, hipStream_t s) {
-  constexpr size_t lds = (size_t)SCAN_NS * 32 * 256 * 2;
+  constexpr size_t lds = (size_t)SCAN_NS * 64 * 256 * 2;
   static DevOnce once_s, once_a, once_f;
   cor_max_dyn_lds((const void*)sim_scan<TG, QB, true>, (int)lds, once_s);
   cor_max_dyn_lds((const void*)sim_scan<TG, QB, false>, (int)lds, once_a);
@@ -742,30 +860,32 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   cor_max_dyn_lds((const void*)sim_final<TG>, (int)fs_lds, once_f);
   float* pmax = (float*)(w + p.off_pmax); float* tau = (float*)(w + p.off_tau);
   int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
-  float* cand_s = (float*)(w + p.off_cs); int* cand_i = (int*)(w + p.off_ci);
+  float* rec_s = (float*)(w + p.off_recs); int* rec_g = (int*)(w + p.off_recg);
+  uint4* qimg = (uint4*)(w + p.off_img);
+  // 0. queries -> gallery dtype, fragment-major; clears the per-call overflow flags
+  hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
+  COR_CHECK_LAUNCH();
   ScanArgs a{};
-  a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg;
+  a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg; a.qimg = qimg;
   if (p.ngroups > 0) {                                  // A. group maxima of the strided sample
     a.nsplit = p.s_nsplit; a.tiles_per_split = p.s_tiles_per_split; a.ntiles = p.s_tiles; a.tile_stride = p.s_stride;
     a.pmax = pmax; a.ngroups = p.ngroups;
-    hipLaunchKernelGGL((sim_scan<TG, QB, true>), dim3(p.nqg * p.s_nsplit), dim3(512), lds, s, Q, G, a);
+    hipLaunchKernelGGL((sim_scan<TG, QB, true>), dim3(p.nqg * p.s_nsplit), dim3(512), lds, s, G, a);
     COR_CHECK_LAUNCH();
   }
-  // B. tau (ngroups == 0: -inf) ; also clears the per-call overflow flags
-  hipLaunchKernelGGL((sim_tau<TG>), dim3(cdiv(Bq, 4)), dim3(256), 0, s, Q, pmax, p.ngroups, Bq, k, tau, dflags, ovf_q);
+  // B. tau (ngroups == 0: -inf)
+  hipLaunchKernelGGL((sim_tau<TG>), dim3(cdiv(Bq, 4)), dim3(256), 0, s, Q, pmax, p.ngroups, Bq, k, tau);
   COR_CHECK_LAUNCH();
   // C. full scan
   a.nsplit = p.nsplit; a.tiles_per_split = p.tiles_per_split; a.ntiles = p.tiles; a.tile_stride = 1;
-  a.tau = tau; a.cnt = cnt; a.cand_s = cand_s; a.cand_i = cand_i; a.cap = p.cap;
-  hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, Q, G, a);
+  a.tau = tau; a.cnt = cnt; a.rec_s = rec_s; a.rec_g = rec_g; a.cap = p.cap; a.tau_add = (flags & 4) ? 1e30f : 0.f;
+  hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, G, a);
   COR_CHECK_LAUNCH();
   // D. exact selection
-  hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, cand_s, cand_i, cnt, p.nstreams, p.cap, k, g_offset, out_s, out_i,
+  hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, rec_s, rec_g, tau, cnt, p.nstreams, p.cap, Ng, k, g_offset, out_s, out_i,
                      dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
   COR_CHECK_LAUNCH();
-  if (flags & COR_TOPK_NO_FALLBACK) return 0;           // overflowed queries keep index -2 (tests)
-  // E. gated fallback: the list kernels exit at once unless sim_final flagged an overflow
-  return launch_lists_v2<TG>(Q, G, Bq, Ng, k, g_offset, out_s, out_i, (float*)(w + p.off_lists), dflags, ovf_q, s);
+  return 0;                                             // (an overflowed query was ranked exactly inside sim_final: no second launch)
 }
 
 template <typename TG>

@@ -13,6 +13,7 @@ import math
 
 import torch
 
+from . import _native as nat
 from . import ops
 from .ops import ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TANH
 
@@ -68,9 +69,16 @@ def pack_sam_encoder(pk: _Packer, cfg: dict, p="image_encoder."):
     for i in range(cfg["depth"]):
         b = f"{p}blocks.{i}."
         pk.ln(b + "norm1."); pk.ln(b + "norm2.")
-        pk.lin(b + "attn.qkv."); pk.lin(b + "attn.proj."); pk.lin(b + "mlp.lin1."); pk.lin(b + "mlp.lin2.")
+        # bf16 MFMA attention (head_dim 64) runs the score product directly in the log2 domain: scale * log2(e) is folded into
+        # the q rows of the qkv projection HERE (one rounding of the scaled weight; nothing at run time). fp32 mode: raw q.
+        qs = nat.Q_PRESCALE_HD64 if (pk.T == torch.bfloat16 and d // cfg["heads"] == 64) else 1.0
+        W[b + "attn.q_prescale"] = qs
+        wq, bq = sd[b + "attn.qkv.weight"].detach().to(F32).clone(), sd[b + "attn.qkv.bias"].detach().to(F32).clone()
+        wq[:d] *= qs; bq[:d] *= qs
+        pk.mat(b + "attn.qkv.weight", wq); pk.f32(b + "attn.qkv.bias", bq)
+        pk.lin(b + "attn.proj."); pk.lin(b + "mlp.lin1."); pk.lin(b + "mlp.lin2.")
         pk.f32(b + "attn.rel_pos_h"); pk.f32(b + "attn.rel_pos_w")
-        pk.mat(b + "attn.pad_row", sd[b + "attn.qkv.bias"])          # qkv of a zero (padded) token
+        pk.mat(b + "attn.pad_row", bq)                               # qkv of a zero (padded) token
     pk.mat(p + "neck.0.weight", sd[p + "neck.0.weight"].detach().reshape(cfg["out"], d))
     pk.ln(p + "neck.1."); pk.ln(p + "neck.3.")
     w3 = sd[p + "neck.2.weight"].detach()                            # [O, C, 3, 3] -> [O, (ky,kx,c)]
@@ -207,7 +215,8 @@ def sam_encoder(W, img, cfg, T, p="image_encoder."):
         win = 0 if i in cfg["global_idx"] else cfg["window"]
         h = _ln(W, b + "norm1.", x, 1e-6, T)                                              # :169
         qkv = _lin(W, b + "attn.qkv.", h, T)                                              # :229
-        a = ops.sam_attention(qkv, W[b + "attn.pad_row"], W[b + "attn.rel_pos_h"], W[b + "attn.rel_pos_w"], B, H, g, win)  # :172-180,232-238
+        a = ops.sam_attention(qkv, W[b + "attn.pad_row"], W[b + "attn.rel_pos_h"], W[b + "attn.rel_pos_w"], B, H, g, win,
+                              q_prescale=W[b + "attn.q_prescale"])                          # :172-180,232-238
         del qkv
         _lin(W, b + "attn.proj.", a, F32, residual=x, out=x)                              # :239,182
         h = _ln(W, b + "norm2.", x, 1e-6, T)

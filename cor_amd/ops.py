@@ -123,7 +123,7 @@ def attention(q, k, v, B, H, Tq, Tk, hd, scale, out_dtype=None):
     return out
 
 
-def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None, variant=0):
+def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None, variant=0, q_prescale=1.0):
     _dev(qkv, pad_row, rel_h, rel_w)
     hd = rel_h.shape[1]
     d = H * hd
@@ -135,7 +135,7 @@ def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None
         assert pad_row is not None and pad_row.dtype == qkv.dtype and pad_row.is_contiguous() and pad_row.numel() == 3 * d
     out = torch.empty((B * grid * grid, d), dtype=out_dtype or qkv.dtype, device=qkv.device)
     nat.check(_lib().cor_sam_attention(qkv.data_ptr(), _dt(qkv), out.data_ptr(), _dt(out), _p(pad_row), rel_h.data_ptr(),
-                                       rel_w.data_ptr(), B, H, hd, grid, window, int(variant), _s()), "cor_sam_attention")
+                                       rel_w.data_ptr(), B, H, hd, grid, window, float(q_prescale), int(variant), _s()), "cor_sam_attention")
     return out
 
 

@@ -74,10 +74,15 @@ int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb,
  * out [B*grid*grid, H*hd]. rel_h / rel_w: [2S-1, hd] fp32.
  * ref: lib/sam_model/image_encoder.py:225-241 (Attention), :244-290 (window partition), :293-362 (rel-pos). */
 int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, const void* pad_row,
-                      const float* rel_h, const float* rel_w, int B, int H, int hd, int grid, int window, int variant, void* stream);
-/* `variant` is a PER-CALL kernel choice for the bf16 MFMA path: 0 = default kernels (global: flash_global_pipe, software-
- * pipelined over key tiles); 1 = the plain chain form of the same arithmetic (flash_fwd<1>), kept as the in-process A/B and
- * parity partner (tests, tools/attn_bench.py). Production callers pass 0. */
+                      const float* rel_h, const float* rel_w, int B, int H, int hd, int grid, int window, float q_prescale, int variant,
+                      void* stream);
+/* `q_prescale`: the factor the caller has ALREADY folded into the q third of qkv (and of pad_row): 1 = raw q (always accepted);
+ * 0.125 * log2(e) (hd 64: scale * log2 e) lets the bf16 MFMA kernels run the score product directly in the log2 domain with
+ * no per-score multiply - the engine folds it into the q rows of the qkv weight / bias at pack time, so it costs nothing at
+ * run time and q is rounded to bf16 once. The rel-pos terms are rescaled accordingly inside (they use the unscaled q).
+ * `variant` is a PER-CALL kernel choice for the bf16 MFMA path: 0 = default kernels (global: flash_global_pipe, software-
+ * pipelined over key tiles; windowed: win_attn, one 7-wave block per (window, head)); 1 = the round-1 chain forms of the same
+ * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py). */
 
 /* ---- data movement / elementwise --------------------------------------------------------------------------- */
 

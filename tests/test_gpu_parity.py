@@ -360,6 +360,62 @@ def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
     report(f"global_attn_pipe_B{B}_H{H}_amp{amp}", out, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,grid,amp,TO", [(1, 12, 64, 1.0, BF16), (3, 16, 64, 1.0, F32), (2, 5, 64, 6.0, BF16), (2, 12, 64, 0.05, BF16),
+                                               (2, 3, 28, 1.0, BF16), (1, 2, 30, 2.0, F32)])
+def test_windowed_attention_block_per_window_vs_chain_kernel(B, H, grid, amp, TO):
+    """win_attn (one 7-wave block per (window, head): bias and running reference folded into the score accumulator, Q
+    pre-scaled in bf16; default) against flash_fwd<2> (round-1 chain form, scale applied in fp32) on the same inputs, and
+    both against an fp64 CPU evaluation of image_encoder.py:225-241,244-290,326-362 on the SAME bf16 operands. Grids 64 (5x5
+    windows, bottom/right padded), 28 (exact 2x2), 30 (3x3 with 12-token padding); amp = 6 drives log2-scores to +-100 (the
+    lazy rescale fires), amp = 0.05 nearly uniform attention. Padded tokens use pad_row (the qkv bias), as the reference's
+    zero-padding after norm1 implies."""
+    ops, _ = _ops()
+    g = torch.Generator(device=DEV).manual_seed(B * 100 + H + grid)
+    d = H * 64
+    qkv = (torch.randn((B * grid * grid, 3 * d), generator=g, device=DEV) * amp).to(BF16)
+    pad = (torch.randn((3 * d,), generator=g, device=DEV) * amp).to(BF16)
+    rh = torch.randn((27, 64), generator=g, device=DEV) * 0.3
+    rw = torch.randn((27, 64), generator=g, device=DEV) * 0.3
+    out = ops.sam_attention(qkv, pad, rh, rw, B, H, grid, 14, out_dtype=TO)
+    out2 = ops.sam_attention(qkv, pad, rh, rw, B, H, grid, 14, out_dtype=TO)
+    old = ops.sam_attention(qkv, pad, rh, rw, B, H, grid, 14, out_dtype=TO, variant=1)
+    assert torch.equal(out, out2)                                   # run-to-run reproducible
+    # fp64 reference on the same bf16 operands (tables rounded to bf16 as both kernels feed them to the MFMA)
+    nW = (grid + 13) // 14
+    P = nW * 14
+    x = pad.double().cpu().repeat(B, P, P, 1)
+    x[:, :grid, :grid] = qkv.double().cpu().view(B, grid, grid, 3 * d)
+    xw = x.view(B, nW, 14, nW, 14, 3, H, 64).permute(0, 1, 3, 5, 6, 2, 4, 7).reshape(B * nW * nW, 3, H, 196, 64)
+    q, k, v = xw[:, 0], xw[:, 1], xw[:, 2]
+    qf_, kf_, vf_ = (t.reshape(-1, 196, 64) for t in (q, k, v))
+    bias = osam.rel_pos_bias(qf_, rh.to(BF16).double().cpu(), rw.to(BF16).double().cpu(), 14)      # oracle (pinned by the goldens)
+    att = (torch.softmax((qf_ * 0.125) @ kf_.transpose(1, 2) + bias, dim=-1) @ vf_).reshape(-1, H, 196, 64)
+    ref = att.reshape(B, nW, nW, H, 14, 14, 64).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, P, P, d)[:, :grid, :grid].reshape(-1, d).float()
+    scale = float(ref.abs().max())
+    # Budgets. The chain form multiplies exact bf16 products by scale*log2e in fp32; win_attn feeds the MFMA q * scale*log2e
+    # ROUNDED to bf16 (one more 2^-9 rounding on the q side). At amp <= 2 (log2-scores within +-25) both sit at ~1e-3 rel-L2;
+    # at amp = 6 the softmax is nearly one-hot, |score| ~ 100 log2 units, the extra rounding moves a score by ~0.1 and a
+    # near-tie between the two best keys by up to ~8 % of the value range: max-abs budget 8e-2 of the scale there (chain form
+    # 2e-2), rel-L2 <= 1.5e-2.
+    hard = amp > 2
+    tol_new = (8e-2 if hard else 2e-2) if TO == BF16 else (8e-2 if hard else 1.2e-2)
+    tol_old = 2e-2 if TO == BF16 else 1.2e-2
+    r_old = report(f"win_attn_old_B{B}_H{H}_g{grid}_amp{amp}_{TO}", old, ref, rtol=0, atol=tol_old * scale)
+    r_new = report(f"win_attn_new_B{B}_H{H}_g{grid}_amp{amp}_{TO}", out, ref, rtol=0, atol=tol_new * scale)
+    _note(name=f"win_attn_relL2_B{B}_H{H}_g{grid}_amp{amp}_{TO}", new=r_new["rel_l2"], old=r_old["rel_l2"])
+    assert r_new["rel_l2"] <= (1.5e-2 if hard else 4e-3 * max(1.0, amp)), (r_new, r_old)
+    # q_prescale path (what the engine runs: scale * log2 e folded into the q third by the caller), both kernel forms
+    from cor_amd import _native as nat
+    c = nat.Q_PRESCALE_HD64
+    qs, ps = qkv.float(), pad.float()
+    qs[:, :d] *= c; ps[:d] *= c
+    qs, ps = qs.to(BF16), ps.to(BF16)
+    for variant in (0, 1):
+        o_p = ops.sam_attention(qs, ps, rh, rw, B, H, grid, 14, out_dtype=TO, variant=variant, q_prescale=c)
+        r_p = report(f"win_attn_prescaled_v{variant}_B{B}_H{H}_g{grid}_amp{amp}_{TO}", o_p, ref, rtol=0, atol=tol_new * scale)
+        assert r_p["rel_l2"] <= (1.5e-2 if hard else 4e-3 * max(1.0, amp)), r_p
+
+
 @pytest.mark.parametrize("window", [14, 0])
 @pytest.mark.parametrize("T", [F32, BF16])
 def test_sam_attention_real_dims(window, T):
@@ -721,8 +777,8 @@ def test_similarity_topk_fp32_bitwise_vs_fma_chain_oracle(Bq, Ng, k):
 
 def test_similarity_topk_candidate_overflow_falls_back_on_the_device():
     """A degenerate gallery (every row identical => every score ties with the threshold) overflows the candidate buffers.
-    sim_final flags the queries ON THE DEVICE and the gated list kernels behind it recompute them: the default call returns
-    the exact answer with no host round trip; COR_TOPK_NO_FALLBACK exposes the raw overflow marker (index -2). A mixed
+    sim_final detects it ON THE DEVICE and the same block ranks the whole shard for that query with the exact fmaf chain: the
+    default call returns the exact answer with no host round trip and no second launch; COR_TOPK_NO_FALLBACK exposes the raw overflow marker (index -2). A mixed
     gallery (degenerate for some queries only) must repair exactly the flagged queries and leave the others bit-exact."""
     ops, _ = _ops()
     from cor_amd import _native as nat
@@ -743,9 +799,9 @@ def test_similarity_topk_candidate_overflow_falls_back_on_the_device():
     flagged = (raw2 == -2).all(dim=1).cpu()
     assert bool(flagged[0]) and int(flagged.sum()) < 40, flagged
     assert torch.equal(i2[0].cpu(), torch.arange(10000, 10010))
-    rs, ri = oret.similarity_topk_chain(Q.to(BF16).float(), G2.float(), 10)
-    keep = ~flagged
-    assert torch.equal(i2.cpu()[keep], ri[keep]) and torch.equal(s2.cpu()[keep].view(torch.int32), rs[keep].view(torch.int32))
+    rs, ri = oret.similarity_topk_chain(Q.to(BF16).float(), G2.float(), 10, margin=1e-3)
+    # the in-kernel fallback ranks the flagged queries with the exact chain too: EVERY query is bit-identical to the oracle
+    assert torch.equal(i2.cpu(), ri) and torch.equal(s2.cpu().view(torch.int32), rs.view(torch.int32))
 
 
 # ======================================================================================================

@@ -16,6 +16,7 @@ SHAPES = ((32, 100000, 10, torch.bfloat16), (32, 12500, 10, torch.bfloat16), (25
           (512, 1000000, 10, torch.bfloat16))
 only_1m = len(sys.argv) > 1 and sys.argv[1] == "1m"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 4: timing-only ablation, no candidate passes the threshold (results invalid)
 if only_1m:
     SHAPES = ((512, 1000000, 10, torch.bfloat16),)
 for Bq, Ng, k, dt in SHAPES:
@@ -24,7 +25,7 @@ for Bq, Ng, k, dt in SHAPES:
     ts = []
     for i in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.similarity_topk(Q, G, k); e1.record(); e1.synchronize()
+        e0.record(); ops.similarity_topk(Q, G, k, flags=flags); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     t = sorted(ts[1:])[len(ts[1:]) // 2] * 1e-3          # median of the warm calls
     fl = 2.0 * Bq * Ng * 256
