@@ -431,7 +431,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 //     had one iteration, about its own global-load latency); one counted wait and one barrier per iteration.
 // LDS = 48 KiB rings + 32 KiB row-bias tables = 80 KiB: two blocks per CU. Tile -1 is a zero V tile with P = 0; the last
 // iteration's S(nt) comes from a stale K tile and is dropped.
-template <typename TO>
+// PRE (q_prescale = scale * log2 e folded into q by the caller, a.scale_log2 == 1): the bias and the running reference are
+// folded INTO the score MFMA - S(t+1)'s accumulators start at  colbias[kw] + rowbias(t+1) - m  (one add per score) and the
+// MFMA result is already  x - m  in the log2 domain, so a score costs  add + max/2 + exp2 + cvt_pk/2  instead of
+// fma + max/2 + sub + exp2 + cvt_pk/2  (the softmax VALU, not the matrix pipe, bounds this kernel).
+template <typename TO, bool PRE>
 __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
@@ -540,7 +544,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) lsum[e] = 0.f;
-  float m = -INFINITY;
+  float m = PRE ? 0.f : -INFINITY;
   const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
   uint4 pf[2][2];
 #pragma unroll
@@ -549,8 +553,9 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   // S(0)
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
+    const float c0 = PRE ? aux[r] : 0.f;                // row bias of key row 0 (reference m = 0 until tile 0 has been seen)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+    for (int e = 0; e < 16; ++e) s[kb][e] = PRE ? wreg[kb][e] + c0 : 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint4 kf = *(const uint4*)(Kring + kb * 32 * 128 + kch[c]);
@@ -567,8 +572,8 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     issue_v(t + 1, c3p1);                               // over V(t-2), last read in iteration t-1
     const char* Vs = Vring + c3p2 * TILE_B;             // V(t-1)
     const char* Ks = Kring + c3p1 * TILE_B;             // K(t+1)
-    const float rh = aux[t * 32 + r];
-    // ---- phase A: PV(t-1) and row-sum MFMAs beside scale + bias + max of S(t)
+    const float rh = PRE ? aux[min(t + 1, nt - 1) * 32 + r] : aux[t * 32 + r];   // PRE: row bias of the NEXT tile (folded into S(t+1))
+    // ---- phase A: PV(t-1) and row-sum MFMAs beside (scale + bias +) max of S(t)
     uint4 vf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -587,42 +592,84 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     float mloc = -INFINITY;
+    f32x16 sn[2];
+    if (PRE) {
+      // max of S(t) and the start values of S(t+1) (column bias + next row bias - CURRENT reference; corrected below in the
+      // rare case that the reference moves), all beside the PV MFMAs
+      const float cinit = rh - m;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const float x0 = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]), x1 = fmaf(s[kb][e + 1], a.scale_log2, wreg[kb][e + 1]);
-        s[kb][e] = x0; s[kb][e + 1] = x1;
-        mloc = fmaxf(mloc, fmaxf(x0, x1));
+        for (int e = 0; e < 16; e += 2) {
+          mloc = fmaxf(mloc, fmaxf(s[kb][e], s[kb][e + 1]));
+          sn[kb][e] = wreg[kb][e] + cinit; sn[kb][e + 1] = wreg[kb][e + 1] + cinit;
+        }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU (16 max + 32 add for 12 MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
       }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {                      // 1 MFMA : 4 VALU
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const float x0 = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]), x1 = fmaf(s[kb][e + 1], a.scale_log2, wreg[kb][e + 1]);
+          s[kb][e] = x0; s[kb][e + 1] = x1;
+          mloc = fmaxf(mloc, fmaxf(x0, x1));
+        }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    mloc = fmaxf(mloc, other_half(mloc)) + rh;          // true tile max (x + rh)
-    if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {       // lazy rescale (see the header)
-      const float mnew = fmaxf(m, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-      m = mnew;
-      lsum[0] *= alpha;
+    float msub = 0.f;
+    if (PRE) {
+      mloc = fmaxf(mloc, other_half(mloc));             // tile maximum of x - m
+      // reference update: always after tile 0 (m = its maximum), later only when a tile maximum exceeds it by 2^8 (lazy rescale)
+      if (t == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
+        const float d = t == 0 ? mloc : fmaxf(mloc, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m += d;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+          for (int e = 0; e < 16; ++e) { s[kb][e] -= d; sn[kb][e] -= d; }
+        lsum[0] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+      }
+    } else {
+      mloc = fmaxf(mloc, other_half(mloc)) + rh;        // true tile max (x + rh)
+      if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {     // lazy rescale (see the header)
+        const float mnew = fmaxf(m, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        lsum[0] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+      }
+      msub = m - rh;                                    // p = 2^(x + rh - m)
     }
-    const float msub = m - rh;                          // p = 2^(x + rh - m)
     // ---- phase B: QK(t+1) MFMAs beside exp2 and packing of P(t)
-    f32x16 sn[2];
     uint4 kf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) kf[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
+    if (!PRE) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), sn[kb], 0, 0, 0);
@@ -631,14 +678,14 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 p;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub);
+      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(PRE ? s[kb][e] : s[kb][e] - msub);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                       // 1 MFMA : 11 VALU
+    for (int i = 0; i < 8; ++i) {                       // 1 MFMA : 11 (PRE: 7) VALU
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 7 : 11, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     s[0] = sn[0]; s[1] = sn[1];
@@ -911,16 +958,24 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO>
-int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
+template <typename TO, bool PRE>
+int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, PRE>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, 128);
-  hipLaunchKernelGGL((flash_global_pipe<TO>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((flash_global_pipe<TO, PRE>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
+}
+// PRE (bias / reference folded into the score accumulator) is NOT the default: measured 2.68-2.78 ms against 2.29-2.44 ms for
+// the fma form on the same boxes at B = 32 (tools/attn_bench.py) although it issues 32 fewer VALU per tile - in this kernel time
+// does not follow the VALU count (see the header); it stays selectable (variant 2) as the in-process A/B partner. The windowed
+// kernel (win_attn), whose blocks are short and VALU-bound, does gain from the same idea.
+template <typename TO>
+int launch_global_pipe(const FlashArgs& a, int nb, bool folded, hipStream_t s) {
+  return (folded && a.scale_log2 == 1.0f) ? launch_global_pipe_<TO, true>(a, nb, s) : launch_global_pipe_<TO, false>(a, nb, s);
 }
 
 template <int MODE, typename TO>
@@ -939,7 +994,8 @@ int launch(const FlashArgs& a, int nb, hipStream_t s) {
 
 // `variant` (per call): 0 (default) = flash_global_pipe (global; software-pipelined over key tiles) / win_attn (windowed; one
 // 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>, the round-1 chain forms of the same arithmetic (kept as
-// the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py).
+// the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py); 2 = global attention with the bias
+// folded into the score accumulator (needs q_prescale = scale * log2 e; measured slower, see launch_global_pipe).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -966,9 +1022,9 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   if (window == 0) {
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
-    if (variant == 0) {
-      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, s);
-      if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, s);
+    if (variant == 0 || variant == 2) {
+      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, variant == 2, s);
+      if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, variant == 2, s);
     }
     if (out_dtype == COR_BF16) return launch<1, bf16_t>(a, B, s);
     if (out_dtype == COR_F32) return launch<1, float>(a, B, s);
@@ -976,7 +1032,7 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   }
   if (window != 14 || ((uintptr_t)pad_row & 15)) return COR_ENOSUPPORT;
   a.S = 14; a.Tq = a.Tk = 196; a.nW = (grid + 13) / 14;
-  if (variant == 0) {                                   // one 7-wave block per (window, head)
+  if (variant != 1) {                                   // one 7-wave block per (window, head)
     if (out_dtype == COR_BF16) return launch_win<bf16_t>(a, B * a.nW * a.nW, s);
     if (out_dtype == COR_F32) return launch_win<float>(a, B * a.nW * a.nW, s);
     return COR_ENOSUPPORT;

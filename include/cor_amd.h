@@ -82,7 +82,8 @@ int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, cons
  * run time and q is rounded to bf16 once. The rel-pos terms are rescaled accordingly inside (they use the unscaled q).
  * `variant` is a PER-CALL kernel choice for the bf16 MFMA path: 0 = default kernels (global: flash_global_pipe, software-
  * pipelined over key tiles; windowed: win_attn, one 7-wave block per (window, head)); 1 = the round-1 chain forms of the same
- * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py). */
+ * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py); 2 = global
+ * attention with the bias folded into the score accumulator (A/B partner; measured slower than 0). */
 
 /* ---- data movement / elementwise --------------------------------------------------------------------------- */
 

@@ -358,6 +358,24 @@ def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
     out2 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32)
     assert torch.equal(out, out2)                                   # run-to-run reproducible
     report(f"global_attn_pipe_B{B}_H{H}_amp{amp}", out, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    # q_prescale path (what the engine runs): scale * log2 e folded into the q third by the caller; bias and running
+    # reference folded into the score accumulator. One more bf16 rounding on the q side than the chain form (which scales in
+    # fp32): at amp = 6 (|score| ~ 100 log2 units, nearly one-hot softmax) that moves near-ties, hence the wider budget there.
+    from cor_amd import _native as nat
+    c = nat.Q_PRESCALE_HD64
+    qs, ps = qkv.float(), pad.float()
+    qs[:, :d] *= c; ps[:d] *= c
+    qs, ps = qs.to(BF16), ps.to(BF16)
+    o_p = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)
+    o_p2 = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)
+    assert torch.equal(o_p, o_p2)
+    o_f = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2)    # bias folded into the accumulator
+    report(f"global_attn_prescaled_folded_B{B}_H{H}_amp{amp}", o_f, ref, rtol=8e-2 if amp > 2 else 2e-2, atol=(8e-2 if amp > 2 else 2e-2) * float(ref.abs().max()))
+    tol = 8e-2 if amp > 2 else 2e-2
+    r_p = report(f"global_attn_prescaled_B{B}_H{H}_amp{amp}", o_p, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+    assert r_p["rel_l2"] <= (2e-2 if amp > 2 else 5e-3), r_p
+    o_c = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=1)    # chain form, prescaled input
+    report(f"global_attn_prescaled_chain_B{B}_H{H}_amp{amp}", o_c, ref, rtol=tol, atol=tol * float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("B,H,grid,amp,TO", [(1, 12, 64, 1.0, BF16), (3, 16, 64, 1.0, F32), (2, 5, 64, 6.0, BF16), (2, 12, 64, 0.05, BF16),

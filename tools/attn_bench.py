@@ -10,13 +10,20 @@ H, g, dev, T = 12, 64, "cuda:0", torch.bfloat16
 d = H * 64
 qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T)
 pad = torch.randn((3 * d,), device=dev).to(T)
-for window, S, variant in ((0, 64, 0), (0, 64, 1), (14, 14, 0), (14, 14, 1)):   # variant: per-call kernel choice (0 = default)
+from cor_amd._native import Q_PRESCALE_HD64 as QC
+for window, S, variant, qp in ((0, 64, 0, QC), (0, 64, 2, QC), (0, 64, 0, 1.0), (0, 64, 1, 1.0), (14, 14, 0, QC), (14, 14, 0, 1.0), (14, 14, 1, 1.0)):   # variant / q_prescale: per-call choices
     rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
+    qk = qkv
+    if qp != 1.0:                                        # the caller folds the factor into q (as engine.pack does): same logits as the raw run
+        qk = qkv.float(); qk[:, :d] *= qp; qk = qk.to(T)
+        pd = pad.float(); pd[:d] *= qp; pd = pd.to(T)
+    else:
+        pd = pad
     ts = []
     for i in range(6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); ops.sam_attention(qkv, pad, rh, rw, B, H, g, window, variant=variant); e1.record(); e1.synchronize()
+        e0.record(); ops.sam_attention(qk, pd, rh, rw, B, H, g, window, variant=variant, q_prescale=qp); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     fl = (4.0 * (g * g) ** 2 * 64 if window == 0 else 25 * 4.0 * 196 ** 2 * 64) * H * B
-    print(json.dumps(dict(window=window, variant=variant, B=B, ms=min(ts[1:]), tflops=fl / (min(ts[1:]) * 1e-3) / 1e12)), flush=True)
+    print(json.dumps(dict(window=window, variant=variant, q_prescale=round(qp, 4), B=B, ms=min(ts[1:]), tflops=fl / (min(ts[1:]) * 1e-3) / 1e12)), flush=True)
