@@ -15,6 +15,7 @@ F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4
 EINVAL, ENOSUPPORT = -1, -2
 TOPK_FORCE_LISTS, TOPK_NO_FALLBACK = 1, 2
+KERNEL_ROWLANE, KERNEL_FEWQ, KERNEL_FLASH_MFMA, KERNEL_FLASH_PIPELINED, KERNEL_WINDOW_BLOCK = 1, 2, 3, 4, 5
 import numpy as _np
 Q_PRESCALE_HD64 = float(_np.float32(0.125) * _np.float32(1.4426950408889634))   # scale * log2(e) for head_dim 64, as a float32
 
@@ -26,6 +27,7 @@ SIGNATURES = {
     "cor_gemm": [_p, _l, _p, _l, _i, _p, _l, _i, _i, _i, _i, _p, _i, _p, _p, _l, _i, _i, _p],
     "cor_layernorm": [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p],
     "cor_attention": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p, _l, _l, _i, _i, _i, _i, _i, _i, _f, _p],
+    "cor_attention_kernel_id": [_i, _i, _i, _i, _i, _i],
     "cor_sam_attention": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "cor_patchify": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "cor_im2col3x3": [_p, _i, _p, _i, _i, _i, _i, _p],

@@ -264,18 +264,34 @@ int dispatch_types(const AttnArgs& a, int nb, int dtype, int out_dtype, hipStrea
 
 // bf16 MFMA kernels (flash_attn.hip); return COR_ENOSUPPORT when the shape is not theirs.
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb,
-                         long v_st, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale,
+                         long v_st, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale,
                          hipStream_t s);
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w,
-                       int B, int H, int grid, int window, float q_prescale, int variant, hipStream_t s);
+                       int B, int H, int hd, int grid, int window, float q_prescale, int variant, hipStream_t s);
+
+// Which kernel family the dispatchers below pick for 16-byte-aligned operands (tests assert that head_dim 72 / 80 and the SAM
+// shapes run on the matrix cores, not on the row-per-lane VALU kernel). sam_window: -1 = cor_attention, 0 = cor_sam_attention
+// global, > 0 = windowed. Returns COR_KERNEL_* or COR_ENOSUPPORT.
+extern "C" int cor_attention_kernel_id(int dtype, int hd, int Tq, int Tk, int sam_window, int grid) {
+  if (sam_window < 0) {
+    if (dtype == COR_BF16 && (hd == 64 || hd == 72 || hd == 80) && Tq >= 64 && Tk >= 64) return COR_KERNEL_FLASH_MFMA;
+    if (hd == 16 && Tq <= 8 && Tk >= 512) return COR_KERNEL_FEWQ;
+    return (hd == 16 || hd == 32 || hd == 64 || hd == 72 || hd == 80) ? COR_KERNEL_ROWLANE : COR_ENOSUPPORT;
+  }
+  if (dtype == COR_BF16 && (hd == 64 || hd == 80)) {
+    if (sam_window == 0 && grid == 64) return hd == 64 ? COR_KERNEL_FLASH_PIPELINED : COR_KERNEL_FLASH_MFMA;
+    if (sam_window == 14) return hd == 64 ? COR_KERNEL_WINDOW_BLOCK : COR_KERNEL_FLASH_MFMA;
+  }
+  return (hd == 16 || hd == 32 || hd == 64 || hd == 80) ? COR_KERNEL_ROWLANE : COR_ENOSUPPORT;
+}
 
 extern "C" int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb,
                              long v_st, int dtype, void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk,
                              int hd, float scale, void* stream) {
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return COR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == COR_BF16 && hd == 64 && Tq >= 64 && Tk >= 64) {
-    const int rc = cor_flash_plain_bf16(q, q_sb, q_st, k, k_sb, k_st, v, v_sb, v_st, out, o_sb, o_st, out_dtype, B, H, Tq, Tk, scale, s);
+  if (dtype == COR_BF16 && (hd == 64 || hd == 72 || hd == 80) && Tq >= 64 && Tk >= 64) {     // bf16 MFMA flash kernels
+    const int rc = cor_flash_plain_bf16(q, q_sb, q_st, k, k_sb, k_st, v, v_sb, v_st, out, o_sb, o_st, out_dtype, B, H, Tq, Tk, hd, scale, s);
     if (rc != COR_ENOSUPPORT) return rc;
   }
   AttnArgs a{};
@@ -315,8 +331,8 @@ extern "C" int cor_sam_attention(const void* qkv, int dtype, void* out, int out_
   if (!(q_prescale > 0.f)) return COR_EINVAL;
   if (window > 0 && !pad_row) return COR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == COR_BF16 && hd == 64) {
-    const int rc = cor_flash_sam_bf16(qkv, out, out_dtype, pad_row, rel_h, rel_w, B, H, grid, window, q_prescale, variant, s);
+  if (dtype == COR_BF16 && (hd == 64 || hd == 80)) {
+    const int rc = cor_flash_sam_bf16(qkv, out, out_dtype, pad_row, rel_h, rel_w, B, H, hd, grid, window, q_prescale, variant, s);
     if (rc != COR_ENOSUPPORT) return rc;
   }
   if (q_prescale != 1.0f) return COR_ENOSUPPORT;       // the row-per-lane kernels take the raw q

@@ -69,52 +69,78 @@ __device__ __forceinline__ uint4 table_frag(const float* tbl, int j, int c, int 
   return pack8(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
 }
 
-// Output store. O^T leaves a query on each lane (32 queries x 64 values per wave): storing it from there is 8 x 8-byte stores
-// per lane that touch 32 different output rows per instruction (16-B pieces) - a store-ISSUE-bound tail (MI355X guide: ~9k
-// cycles; 61 % of a windowed block's lifetime was prologue + this tail). Instead the wave transposes its tile through 4.6 KB of
-// its own LDS (row stride 144 B: conflict-free for both passes) and each instruction stores 8 whole 128-byte rows.
-// off(j) = element offset of local query j's output row, or -1 when that query does not exist.
-template <typename TO, typename OFF>
-__device__ __forceinline__ void store_o_rows(const f32x16 (&o)[2], float inv, char* stg, TO* out, int lane, OFF&& off) {
+// Output store. O^T leaves a query on each lane (32 queries x HD values per wave): storing it from there is 8-byte stores that
+// touch 32 different output rows per instruction - a store-ISSUE-bound tail (MI355X guide: ~9k cycles; 61 % of a windowed
+// block's lifetime was prologue + this tail). Instead the wave transposes its tile through its own LDS (row stride = row bytes
+// + 16: conflict-free for both passes) and each instruction stores whole rows. HD = 64 (2 column blocks of 32), 72 or 80
+// (3 blocks, the third partly empty). off(j) = element offset of local query j's output row, or -1 when that query does not exist.
+template <typename TO, int HD, typename OFF>
+__device__ __forceinline__ void store_o_rows(const f32x16 (&o)[(HD + 31) / 32], float inv, char* stg, TO* out, int lane, OFF&& off) {
+  constexpr int DB = (HD + 31) / 32;
   const int r = lane & 31, h = lane >> 5;
   if constexpr (sizeof(TO) == 2) {
+    constexpr int SR = HD * 2 + 16, NCHO = HD * 2 / 16;           // staging row stride (B), 16-B pieces per output row
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        uint2 u;
-        u.x = pk2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv); u.y = pk2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-        *(uint2*)(stg + r * 144 + (db * 32 + 8 * g + 4 * h) * 2) = u;
+        if (db * 32 + 8 * g + 8 <= HD) {                            // columns db*32 + 8g + 4h .. +3 exist (same for both halves)
+          uint2 u;
+          u.x = pk2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv); u.y = pk2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *(uint2*)(stg + r * SR + (db * 32 + 8 * g + 4 * h) * 2) = u;
+        }
       }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // lanes exchange data through LDS (compiler-only fence)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = (lane >> 3) + 8 * i, ch = lane & 7;
-      const uint4 v = *(const uint4*)(stg + j * 144 + ch * 16);
-      const long e = off(j);
-      if (e >= 0) *(uint4*)(out + e + ch * 8) = v;
+    for (int i = 0; i < (32 * NCHO + 63) / 64; ++i) {
+      const int idx = lane + 64 * i, j = idx / NCHO, ch = idx - j * NCHO;
+      if (idx < 32 * NCHO) {
+        const uint4 v = *(const uint4*)(stg + j * SR + ch * 16);
+        const long e = off(j);
+        if (e >= 0) *(uint4*)(out + e + ch * 8) = v;
+      }
     }
   } else {
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {                   // fp32 rows are 256 B: one 128-B half per pass
+    for (int db = 0; db < DB; ++db) {                   // fp32 rows: one 128-B block of 32 columns per pass
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 v4 = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
-        *(f32x4*)(stg + r * 144 + (8 * g + 4 * h) * 4) = v4;
+        if (db * 32 + 8 * g + 8 <= HD) {
+          const f32x4 v4 = {o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+          *(f32x4*)(stg + r * 144 + (8 * g + 4 * h) * 4) = v4;
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = (lane >> 3) + 8 * i, ch = lane & 7;
         const f32x4 v = *(const f32x4*)(stg + j * 144 + ch * 16);
         const long e = off(j);
-        if (e >= 0) *(f32x4*)(out + e + db * 32 + ch * 4) = v;
+        if (e >= 0 && db * 32 + 4 * ch + 4 <= HD) *(f32x4*)(out + e + db * 32 + ch * 4) = v;
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
 }
 
-template <int MODE, typename TO>
+// A fragment of an fp32 [rows, HD] rel-pos table for K-step c, zero beyond HD (HD = 72: the fifth K-step is half empty)
+template <int HD>
+__device__ __forceinline__ uint4 table_frag_hd(const float* tbl, int j, int c, int h) {
+  if (16 * c + 8 * h + 8 > HD) return make_uint4(0, 0, 0, 0);
+  const float* p = tbl + (long)j * HD + 16 * c + 8 * h;
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  return pack8(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+}
+
+// HD = 64 (SAM-B/L, SigLIP-B/L), 72 (SigLIP SO400M/14: the factory's default tower) or 80 (SAM-H). For 72 / 80 the score
+// product runs 5 K-steps (the operand rows are zero-padded to 80 values) and O^T has 3 column blocks of 32; K / V tiles sit in
+// LDS with 208-byte rows (13 sixteen-byte slots: any 16 consecutive rows hit 16 distinct slots, so no swizzle is needed).
+template <int MODE, typename TO, int HD = 64>
 __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = (HD + 15) / 16, DB = (HD + 31) / 32, NCH = HD * 2 / 16, NCHP = 2 * KS;
+  constexpr int ROWB = HD == 64 ? 128 : 208, TILEB = KT * ROWB, KVB = 4 * TILEB;
+  constexpr int NP = (KT * NCHP + 255) / 256;               // staging passes of 256 sixteen-byte pieces
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   // XCD-aware placement: the nqt query tiles of one (batch, head) re-read the same K/V (1 MiB at 4096 keys); hand each
@@ -132,8 +158,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   // (K,V) row pointers of key index kidx (already clamped to [0, Tk))
   auto kv_src = [&](int kidx, const bf16_t*& kp, const bf16_t*& vp) {
     if (MODE == 0) {
-      kp = a.k + bz * a.k_sb + (long)kidx * a.k_st + head * 64;
-      vp = a.v + bz * a.v_sb + (long)kidx * a.v_st + head * 64;
+      kp = a.k + bz * a.k_sb + (long)kidx * a.k_st + head * HD;
+      vp = a.v + bz * a.v_sb + (long)kidx * a.v_st + head * HD;
     } else {
       long row; bool ok = true;
       if (MODE == 1) row = (long)b * g2 + kidx;
@@ -143,8 +169,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
         row = (long)b * g2 + (long)y * a.grid + x;
       }
       const bf16_t* base = ok ? a.q + row * a.d3 : a.pad_row;
-      kp = base + a.H * 64 + head * 64;
-      vp = base + 2 * a.H * 64 + head * 64;
+      kp = base + a.H * HD + head * HD;
+      vp = base + 2 * a.H * HD + head * HD;
     }
   };
 
@@ -155,47 +181,56 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   const int qh = MODE == 0 ? 0 : tq / S, qw = MODE == 0 ? 0 : tq - (tq / S) * S;
   const bf16_t* qp;
   long orow = 0;
-  if (MODE == 0) qp = a.q + bz * a.q_sb + (long)tq * a.q_st + head * 64;
-  else if (MODE == 1) { orow = (long)b * g2 + tq; qp = a.q + orow * a.d3 + head * 64; }
+  if (MODE == 0) qp = a.q + bz * a.q_sb + (long)tq * a.q_st + head * HD;
+  else if (MODE == 1) { orow = (long)b * g2 + tq; qp = a.q + orow * a.d3 + head * HD; }
   else {
     const int y = wy * S + qh, x = wx * S + qw;
     const bool ok = y < a.grid && x < a.grid;
     qvalid = qvalid && ok;
     orow = (long)b * g2 + (long)min(y, a.grid - 1) * a.grid + min(x, a.grid - 1);
-    qp = ok ? a.q + orow * a.d3 + head * 64 : a.pad_row + head * 64;
+    qp = ok ? a.q + orow * a.d3 + head * HD : a.pad_row + head * HD;
   }
-  uint4 qf[4];
+  uint4 qf[KS];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) qf[c] = *(const uint4*)(qp + 16 * c + 8 * h);
+  for (int c = 0; c < KS; ++c) qf[c] = (16 * c + 8 * h + 8 <= HD) ? *(const uint4*)(qp + 16 * c + 8 * h) : make_uint4(0, 0, 0, 0);
 
   // ---- staging map. Windowed mode: a tile is 4 whole key rows of the 14x14 window (56 keys; LDS rows 56..63 are
   // loaded but masked), so a score's (key row, key column) inside the tile is a compile-time property of its register.
+  // Piece idx = tid + 256 p covers LDS row idx / NCHP, 16-byte slot idx % NCHP; slots >= NCH (HD = 72: slot 9) are zero.
   constexpr int TSTRIDE = MODE == 2 ? 56 : KT;
-  const int srow = tid >> 3, sch = tid & 7;                 // rows srow and srow+32
-  const int k_st0 = srow * 128 + ((sch ^ ((srow >> 1) & 7)) << 4);
-  const int k_st1 = (srow + 32) * 128 + ((sch ^ (((srow + 32) >> 1) & 7)) << 4);
-  const int v_st0 = srow * 128 + sch * 16, v_st1 = (srow + 32) * 128 + sch * 16;
-  uint4 rk0, rk1, rv0, rv1;
-#define FA_GLOAD(T_)                                                                   \
-  {                                                                                    \
-    const bf16_t *kp_, *vp_;                                                           \
-    kv_src(min((T_) * TSTRIDE + srow, a.Tk - 1), kp_, vp_);                            \
-    rk0 = *(const uint4*)(kp_ + sch * 8); rv0 = *(const uint4*)(vp_ + sch * 8);        \
-    kv_src(min((T_) * TSTRIDE + srow + 32, a.Tk - 1), kp_, vp_);                       \
-    rk1 = *(const uint4*)(kp_ + sch * 8); rv1 = *(const uint4*)(vp_ + sch * 8);        \
+  int st_row[NP], st_ch[NP], st_k[NP], st_v[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = tid + 256 * p, row = idx / NCHP, ch = idx - row * NCHP;
+    st_row[p] = row; st_ch[p] = ch;
+    st_k[p] = row * ROWB + (HD == 64 ? ((ch ^ ((row >> 1) & 7)) << 4) : ch * 16);
+    st_v[p] = row * ROWB + ch * 16;
   }
-#define FA_LSTORE(BUF_)                                                                \
-  {                                                                                    \
-    char* Ks_ = smem + (BUF_) * 2 * TILE_B; char* Vs_ = Ks_ + TILE_B;                  \
-    *(uint4*)(Ks_ + k_st0) = rk0; *(uint4*)(Ks_ + k_st1) = rk1;                        \
-    *(uint4*)(Vs_ + v_st0) = rv0; *(uint4*)(Vs_ + v_st1) = rv1;                        \
+  uint4 rk[NP], rv[NP];
+#define FA_GLOAD(T_)                                                                         \
+  {                                                                                          \
+    _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) {                                      \
+      rk[p_] = make_uint4(0, 0, 0, 0); rv[p_] = make_uint4(0, 0, 0, 0);                      \
+      if ((KT * NCHP) % 256 == 0 || tid + 256 * p_ < KT * NCHP) {                            \
+        const bf16_t *kp_, *vp_;                                                             \
+        kv_src(min((T_) * TSTRIDE + st_row[p_], a.Tk - 1), kp_, vp_);                        \
+        if (NCH == NCHP || st_ch[p_] < NCH) { rk[p_] = *(const uint4*)(kp_ + st_ch[p_] * 8); rv[p_] = *(const uint4*)(vp_ + st_ch[p_] * 8); } \
+      }                                                                                      \
+    }                                                                                        \
+  }
+#define FA_LSTORE(BUF_)                                                                      \
+  {                                                                                          \
+    char* Ks_ = smem + (BUF_) * 2 * TILEB; char* Vs_ = Ks_ + TILEB;                          \
+    _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) {                                      \
+      if ((KT * NCHP) % 256 == 0 || tid + 256 * p_ < KT * NCHP) { *(uint4*)(Ks_ + st_k[p_]) = rk[p_]; *(uint4*)(Vs_ + st_v[p_]) = rv[p_]; } \
+    }                                                                                        \
   }
   // tile 0's global loads are issued here, before the rel-pos table work, so that their latency (~2 us, a fifth of a
   // windowed block's lifetime) overlaps it; the registers are written to LDS after the tables (which alias the K/V buffers).
   FA_GLOAD(0)
 
   // ---- relative-position tables (log2 domain)
-  float* aux = (float*)(smem + KV_BYTES + wave * AUX_PER_WAVE);
+  float* aux = (float*)(smem + KVB + wave * AUX_PER_WAVE);
   float wreg[2][16];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -215,14 +250,15 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
           for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
           const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
+          for (int c = 0; c < KS; ++c)
+            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag_hd<HD>(table, j, c, h)),
                                                               __builtin_bit_cast(bf16x8, qf[c]), acc[jb], 0, 0, 0);
         }
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
           for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (tbl == 0) {
 #pragma unroll 4
           for (int i = 0; i < 32; ++i) {
@@ -238,6 +274,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
               if ((j >> 6) == half) wreg[kb][e] = scr[(j & 63) * 32 + r];
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
     __syncthreads();
@@ -250,12 +287,13 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       const int j = min(r, 2 * S - 2);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
+      for (int c = 0; c < KS; ++c)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag_hd<HD>(table, j, c, h)),
                                                       __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < 16; ++e) aux[tbl * 1024 + acc_row(e, h) * 32 + r] = acc[e] * a.tbl_scale;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // column part of the bias for this lane's 32 score registers: constant over tiles -> registers
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -269,15 +307,15 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 
   // ---- fragment read maps
   const int sw = (lane >> 1) & 7;
-  int kch[4];
+  int kch[KS];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) kch[c] = r * 128 + (((2 * c + h) ^ sw) << 4);
+  for (int c = 0; c < KS; ++c) kch[c] = r * ROWB + (HD == 64 ? (((2 * c + h) ^ sw) << 4) : (2 * c + h) * 16);
   // transposed V read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block
-  const int v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int v_tr = (4 * h + ((lane & 15) >> 2)) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-  f32x16 o[2];
+  f32x16 o[DB];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
   float m = -INFINITY;
@@ -292,22 +330,22 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     const bool more = t + 1 < nt;
     if (more) FA_GLOAD(t + 1)
-    const char* Ks = smem + (t & 1) * 2 * TILE_B; const char* Vs = Ks + TILE_B;
+    const char* Ks = smem + (t & 1) * 2 * TILEB; const char* Vs = Ks + TILEB;
 
-    // S^T = K . Q^T. All eight K fragments are read before the MFMAs (a read placed right before its MFMA exposes the LDS latency
-    // once per MFMA; see flash_global_pipe).
+    // S^T = K . Q^T. All K fragments of a 32-key block are read before its MFMAs (a read placed right before its MFMA exposes the
+    // LDS latency once per MFMA; see flash_global_pipe).
     f32x16 s[2];
-    uint4 kfr[8];
+    uint4 kfr[2 * KS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kfr[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
+    for (int i = 0; i < 2 * KS; ++i) kfr[i] = *(const uint4*)(Ks + (i / KS) * 32 * ROWB + kch[i % KS]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
+      for (int c = 0; c < KS; ++c)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[kb * KS + c]), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
     }
     // logits in the log2 domain. MODE 1: the per-tile row term rh is the same for all 64 keys of the tile, so it is
     // folded into the running-max bookkeeping instead of being added to 32 registers. MODE 2: the tile holds key rows
@@ -358,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       m = mnew;
       lsum[0] *= alpha;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+      for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
     }
@@ -372,24 +410,24 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
-    // O^T += V^T . P^T (all eight transposed V fragments first), row sums of P on the matrix pipe: ones . P^T leaves
-    // sum_k P[k][q] (over the bf16-rounded P, as the numerator) in every row of lsum - 32 VALU adds per tile saved
-    uint4 vfr[8];
+    // O^T += V^T . P^T, one 16-key K-step at a time (its DB transposed V fragments first); row sums of P on the matrix pipe:
+    // ones . P^T leaves sum_k P[k][q] (over the bf16-rounded P, as the numerator) in every row of lsum
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
-      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + db * 64 + v_tr;
-      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
-      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
-      const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
-      vfr[i] = make_uint4(u0.x, u0.y, u1.x, u1.y);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kb = kk >> 1, ks = kk & 1;
+      uint4 vfr[DB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
-      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-      if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
+      for (int db = 0; db < DB; ++db) {
+        const char* vb = Vs + (kb * 32 + ks * 16) * ROWB + db * 64 + v_tr;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * ROWB));
+        const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+        vfr[db] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[db]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
+      lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     if (more) FA_LSTORE((t + 1) & 1)
     __syncthreads();
@@ -399,19 +437,21 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   const int nfull = (a.Tk % TSTRIDE) ? nt - 1 : nt;
   for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
   if (nfull < nt) tile(nt - 1, std::true_type{});
+#undef FA_GLOAD
+#undef FA_LSTORE
 
   const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
   // staging: the K/V buffers (every wave is past the last tile's barrier), 8 KiB per wave
   auto off = [&](int j) -> long {
     const int tj = qt_ * 128 + wave * 32 + j;
     if (tj >= a.Tq) return -1;
-    if (MODE == 0) return bz * a.o_sb + (long)tj * a.o_st + head * 64;
-    if (MODE == 1) return ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64;
+    if (MODE == 0) return bz * a.o_sb + (long)tj * a.o_st + head * HD;
+    if (MODE == 1) return ((long)b * g2 + tj) * (long)(a.H * HD) + head * HD;
     const int y = wy * S + tj / S, x = wx * S + (tj - (tj / S) * S);
     if (y >= a.grid || x >= a.grid) return -1;
-    return ((long)b * g2 + (long)y * a.grid + x) * (long)(a.H * 64) + head * 64;
+    return ((long)b * g2 + (long)y * a.grid + x) * (long)(a.H * HD) + head * HD;
   };
-  store_o_rows<TO>(o, inv, smem + wave * 8192, (TO*)a.o, lane, off);
+  store_o_rows<TO, HD>(o, inv, smem + wave * 8192, (TO*)a.o, lane, off);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -720,7 +760,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     const int tj = qt_ * 128 + wave * 32 + j;
     return tj < a.Tq ? ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64 : -1L;
   };
-  store_o_rows<TO>(o, inv, (char*)aux, (TO*)a.o, lane, off);       // the wave's row-bias table is dead: 8 KiB of private staging
+  store_o_rows<TO, 64>(o, inv, (char*)aux, (TO*)a.o, lane, off);   // the wave's row-bias table is dead: 8 KiB of private staging
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -978,16 +1018,23 @@ int launch_global_pipe(const FlashArgs& a, int nb, bool folded, hipStream_t s) {
   return (folded && a.scale_log2 == 1.0f) ? launch_global_pipe_<TO, true>(a, nb, s) : launch_global_pipe_<TO, false>(a, nb, s);
 }
 
-template <int MODE, typename TO>
+template <int MODE, typename TO, int HD = 64>
 int launch(const FlashArgs& a, int nb, hipStream_t s) {
-  const size_t lds = KV_BYTES + (MODE == 0 ? 0 : 4 * AUX_PER_WAVE);
+  constexpr int ROWB = HD == 64 ? 128 : 208;
+  const size_t lds = 4 * KT * ROWB + (MODE == 0 ? 0 : 4 * AUX_PER_WAVE);      // K0 V0 K1 V1 (+ per-wave rel-pos tables)
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_fwd<MODE, TO>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_fwd<MODE, TO, HD>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, 128);
-  hipLaunchKernelGGL((flash_fwd<MODE, TO>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((flash_fwd<MODE, TO, HD>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
+}
+template <int MODE, int HD>
+int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
+  if (out_dtype == COR_BF16) return launch<MODE, bf16_t, HD>(a, nb, s);
+  if (out_dtype == COR_F32) return launch<MODE, float, HD>(a, nb, s);
+  return COR_ENOSUPPORT;
 }
 
 }  // namespace
@@ -997,7 +1044,7 @@ int launch(const FlashArgs& a, int nb, hipStream_t s) {
 // the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py); 2 = global attention with the bias
 // folded into the score accumulator (needs q_prescale = scale * log2 e; measured slower, see launch_global_pipe).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
-                         void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, float scale, hipStream_t s) {
+                         void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
   if ((q_st | k_st | v_st | q_sb | k_sb | v_sb) & 7) return COR_ENOSUPPORT;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return COR_ENOSUPPORT;
@@ -1006,22 +1053,25 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = out;
   a.q_sb = q_sb; a.q_st = q_st; a.k_sb = k_sb; a.k_st = k_st; a.v_sb = v_sb; a.v_st = v_st; a.o_sb = o_sb; a.o_st = o_st;
   a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale_log2 = scale * LOG2E; a.tbl_scale = LOG2E; a.S = 1; a.grid = 1; a.nW = 1;
-  if (out_dtype == COR_BF16) return launch<0, bf16_t>(a, B, s);
-  if (out_dtype == COR_F32) return launch<0, float>(a, B, s);
+  if (hd == 64) return launch_t<0, 64>(a, B, out_dtype, s);
+  if (hd == 72) return launch_t<0, 72>(a, B, out_dtype, s);       // SigLIP SO400M/14 (the factory's default tower)
+  if (hd == 80) return launch_t<0, 80>(a, B, out_dtype, s);
   return COR_ENOSUPPORT;
 }
 
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w, int B,
-                       int H, int grid, int window, float q_prescale, int variant, hipStream_t s) {
+                       int H, int hd, int grid, int window, float q_prescale, int variant, hipStream_t s) {
+  if (hd != 64 && hd != 80) return COR_ENOSUPPORT;     // SAM-B/L: 64, SAM-H: 80
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
   a.q = (const bf16_t*)qkv; a.o = out; a.H = H;
-  a.scale_log2 = 0.125f * LOG2E / q_prescale; a.tbl_scale = LOG2E / q_prescale;
-  if (fabsf(a.scale_log2 - 1.0f) < 1e-6f) { a.scale_log2 = 1.0f; a.tbl_scale = 8.0f; }   // q_prescale = 0.125 * log2(e): exact constants
-  a.pad_row = (const bf16_t*)pad_row; a.rel_h = rel_h; a.rel_w = rel_w; a.grid = grid; a.d3 = 3 * H * 64;
+  a.scale_log2 = LOG2E / sqrtf((float)hd) / q_prescale; a.tbl_scale = LOG2E / q_prescale;
+  if (hd == 64 && fabsf(a.scale_log2 - 1.0f) < 1e-6f) { a.scale_log2 = 1.0f; a.tbl_scale = 8.0f; }   // q_prescale = 0.125 * log2(e): exact constants
+  a.pad_row = (const bf16_t*)pad_row; a.rel_h = rel_h; a.rel_w = rel_w; a.grid = grid; a.d3 = 3 * H * hd;
   if (window == 0) {
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
+    if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
     if (variant == 0 || variant == 2) {
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, variant == 2, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, variant == 2, s);
@@ -1032,6 +1082,7 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   }
   if (window != 14 || ((uintptr_t)pad_row & 15)) return COR_ENOSUPPORT;
   a.S = 14; a.Tq = a.Tk = 196; a.nW = (grid + 13) / 14;
+  if (hd == 80) return launch_t<2, 80>(a, B * a.nW * a.nW, out_dtype, s);
   if (variant != 1) {                                   // one 7-wave block per (window, head)
     if (out_dtype == COR_BF16) return launch_win<bf16_t>(a, B * a.nW * a.nW, s);
     if (out_dtype == COR_F32) return launch_win<float>(a, B * a.nW * a.nW, s);

@@ -58,7 +58,8 @@ int cor_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float*
 /* ---- attention -------------------------------------------------------------------------------------------- */
 
 /* out[b,t,h,:] = softmax_k(scale * q[b,t,h,:].k[b,k,h,:]) v ; element (b,t,h,c) of X lives at
- * X + b*x_sb + t*x_st + h*hd + c (strides in elements). hd in {16,32,64,72,80}.
+ * X + b*x_sb + t*x_st + h*hd + c (strides in elements). hd in {16,32,64,72,80}; bf16 with hd 64 / 72 / 80 and >= 64 queries and
+ * keys runs the MFMA flash kernel (72 = SigLIP SO400M/14, the factory's default tower), everything else the row-per-lane kernel.
  * ref: lib/sam_model/transformer.py:218-240 (decoder Attention), SigLIP towers' MHA. */
 int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st,
                   const void* v, long v_sb, long v_st, int dtype,
@@ -66,7 +67,7 @@ int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb,
                   int B, int H, int Tq, int Tk, int hd, float scale, void* stream);
 
 /* SAM ViTDet attention on the fused qkv activation [B*grid*grid, 3*H*hd] (q|k|v, head-major inside each;
- * hd = 64 for SAM-B/L (bf16: MFMA flash kernels), 80 for SAM-H and 16/32 for reduced test models (row-per-lane kernel)):
+ * hd = 64 for SAM-B/L and 80 for SAM-H (bf16: MFMA flash kernels), 16/32 for reduced test models (row-per-lane kernel)):
  * logits = (q*hd^-0.5).k + q.Rh[qh-kh+S-1] + q.Rw[qw-kw+S-1] (rel-pos from the UNSCALED q).
  * window == 0: global attention over the grid (S = grid). window > 0: non-overlapping window x window tiles of the
  * grid zero-padded bottom/right to a multiple of `window` AFTER norm1, so a padded token's q/k/v equal the qkv
@@ -84,6 +85,11 @@ int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, cons
  * pipelined over key tiles; windowed: win_attn, one 7-wave block per (window, head)); 1 = the round-1 chain forms of the same
  * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py); 2 = global
  * attention with the bias folded into the score accumulator (A/B partner; measured slower than 0). */
+
+/* Which kernel family cor_attention (sam_window = -1) / cor_sam_attention (0 = global, > 0 = windowed) runs for 16-byte-aligned
+ * operands of this shape: bf16 with head_dim 64 / 72 / 80 is on the matrix cores. Pure function (no launch). */
+enum { COR_KERNEL_ROWLANE = 1, COR_KERNEL_FEWQ = 2, COR_KERNEL_FLASH_MFMA = 3, COR_KERNEL_FLASH_PIPELINED = 4, COR_KERNEL_WINDOW_BLOCK = 5 };
+int cor_attention_kernel_id(int dtype, int hd, int Tq, int Tk, int sam_window, int grid);
 
 /* ---- data movement / elementwise --------------------------------------------------------------------------- */
 

@@ -283,10 +283,19 @@ def test_im2col3x3():
 # attention
 # ======================================================================================================
 @pytest.mark.parametrize("hd,H,Tq,Tk", [(16, 8, 6, 4096), (16, 8, 4096, 6), (32, 8, 6, 6), (64, 12, 576, 576), (64, 12, 64, 64),
-                                         (72, 16, 100, 729), (64, 2, 200, 333), (80, 2, 70, 130)])
+                                         (72, 16, 100, 729), (64, 2, 200, 333), (80, 2, 70, 130), (72, 16, 729, 729), (80, 16, 300, 257),
+                                         (72, 3, 64, 64)])
 @pytest.mark.parametrize("T", [F32, BF16])
 def test_attention_plain(hd, H, Tq, Tk, T):
+    """bf16 with head_dim 64 / 72 (SigLIP SO400M/14, the factory default) / 80 must run the MFMA flash kernel (asserted through
+    cor_attention_kernel_id), fp32 the exact row-per-lane kernel."""
     ops, _ = _ops()
+    from cor_amd import _native as nat
+    kid = nat.load().cor_attention_kernel_id(nat.BF16 if T == BF16 else nat.F32, hd, Tq, Tk, -1, 0)
+    if T == BF16 and hd in (64, 72, 80) and Tq >= 64 and Tk >= 64:
+        assert kid == nat.KERNEL_FLASH_MFMA, kid
+    else:
+        assert kid in (nat.KERNEL_ROWLANE, nat.KERNEL_FEWQ), kid
     rng = np.random.default_rng(hd + Tq + Tk)
     B, D = 2, H * hd
     q = torch.from_numpy(rng.standard_normal((B * Tq, D), dtype=np.float32)).to(T)
@@ -435,11 +444,18 @@ def test_windowed_attention_block_per_window_vs_chain_kernel(B, H, grid, amp, TO
 
 
 @pytest.mark.parametrize("window", [14, 0])
-@pytest.mark.parametrize("T", [F32, BF16])
-def test_sam_attention_real_dims(window, T):
-    """hd 64, grid 64 (window 14 -> 5x5 padded windows; 0 -> global 4096 keys) against the oracle."""
+@pytest.mark.parametrize("T,hd", [(F32, 64), (BF16, 64), (BF16, 80)])
+def test_sam_attention_real_dims(window, T, hd):
+    """hd 64 (SAM-B/L) and 80 (SAM-H), grid 64 (window 14 -> 5x5 padded windows; 0 -> global 4096 keys) against the oracle.
+    bf16 must run on the matrix cores for both head dims (cor_attention_kernel_id)."""
     ops, _ = _ops()
-    heads, dim, grid, B = 2, 128, 64, 1
+    from cor_amd import _native as nat
+    heads, dim, grid, B = 2, 2 * hd, 64, 1
+    kid = nat.load().cor_attention_kernel_id(nat.BF16 if T == BF16 else nat.F32, hd, 0, 0, window, grid)
+    if T == BF16:
+        assert kid in (nat.KERNEL_FLASH_MFMA, nat.KERNEL_FLASH_PIPELINED, nat.KERNEL_WINDOW_BLOCK), kid
+    else:
+        assert kid == nat.KERNEL_ROWLANE
     cfg = dict(dim=dim, heads=heads, depth=1, global_idx=(0,) if window == 0 else (), window=14, img=1024, patch=16, out=16)
     spec = {k: v for k, v in ocfg.sam_encoder_spec(cfg, "e.").items() if k.startswith("e.blocks.0.attn.")}
     sd = ocfg.random_state(spec, 31)
@@ -459,7 +475,7 @@ def test_sam_attention_real_dims(window, T):
     qkv = ops.gemm(xd, d[p + "qkv.weight"].to(T), bias=d[p + "qkv.bias"])
     a = ops.sam_attention(qkv, d[p + "qkv.bias"].to(T), d[p + "rel_pos_h"], d[p + "rel_pos_w"], B, heads, grid, window)
     y = ops.gemm(a, d[p + "proj.weight"].to(T), out_dtype=F32, bias=d[p + "proj.bias"])
-    report(f"sam_attention_hd64_w{window}_{T}", y.view(B, grid, grid, dim), ref,
+    report(f"sam_attention_hd{hd}_w{window}_{T}", y.view(B, grid, grid, dim), ref,
            **(dict(rtol=1e-3, atol=2e-4) if T == F32 else dict(rtol=5e-2, atol=5e-2)))
 
 
