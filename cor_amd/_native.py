@@ -50,6 +50,7 @@ SIGNATURES = {
     "cor_iou_select": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "cor_mask_prob_minmax": [_p, _p, _i, _i, _p],
     "cor_resize_binarize": [_p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cor_resize_gray": [_p, _p, _i, _i, _i, _i, _i, _p],
     "cor_resample_rows_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "cor_resample_cols_u8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "cor_mask_metrics": [_p, _p, _p, _i, _i, _f, _p],

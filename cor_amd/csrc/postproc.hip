@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(256) resize_binarize_kernel(const float* p, un
     const float wy = sy - (float)y0, wx = sx - (float)x0;
     const float top = src[y0 * W + x0] * (1.f - wx) + src[y0 * W + x1] * wx;
     const float bot = src[y1 * W + x0] * (1.f - wx) + src[y1 * W + x1] * wx;
-    dst[i] = (top * (1.f - wy) + bot * wy) > thr ? 255 : 0;
+    const float v = top * (1.f - wy) + bot * wy;
+    // thr >= 0: hard mask (> thr ? 255 : 0); thr < 0: soft mask, (v * 255).astype(uint8) = truncation (utils/vailder.py:621)
+    dst[i] = thr >= 0.f ? (v > thr ? 255 : 0) : (unsigned char)fminf(fmaxf(v * 255.f, 0.f), 255.f);
   }
 }
 
@@ -82,6 +84,10 @@ extern "C" int cor_resize_binarize(const float* prob, unsigned char* out, int B,
   hipLaunchKernelGGL(resize_binarize_kernel, dim3((int)blocks, B), dim3(256), 0, (hipStream_t)stream, prob, out, H, W, OH, OW, threshold);
   COR_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int cor_resize_gray(const float* prob, unsigned char* out, int B, int H, int W, int OH, int OW, void* stream) {
+  return cor_resize_binarize(prob, out, B, H, W, OH, OW, -1.0f, stream);
 }
 
 extern "C" int cor_mask_metrics(const float* pred, const float* gt, float* out, int B, int HW, float smooth, void* stream) {

@@ -3,6 +3,7 @@
 Same entry points, arguments and file outputs as the reference:
   * save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, dataset_path=..., pred_save_dir=...)
         utils/vailder.py:368-510 — sigmoid -> per-sample min-max -> resize to the ground-truth size -> > 0.5 -> PNG
+  * save_soft_pred_masks(...)   utils/vailder.py:513-656 — the same with grayscale output ((pred * 255).astype(uint8))
   * val_metric(test_loader, model, opt, logger, accelerator=None, output_csv_name=...)
         utils/vailder.py:13-221 (commented out in the shipped reference, restored here) with the metric definitions of
         utils/trainer_v3_g.py:381-443 — per-sample CSV + global Dice / MAE / IoU / mDice / mIoU
@@ -45,10 +46,15 @@ def _is_main(accelerator):
     return True if accelerator is None else bool(accelerator.is_main_process)
 
 
-def _autocast(accelerator):
+def _autocast(accelerator, opt=None):
+    """accelerator.autocast() like the reference; without accelerate the precision comes from the config key `mixed_precision`
+    ("bf16" = config/vaild_config/vaild_a.yaml:4, the default; "no" = the exact fp32 MFMA mode)."""
     if accelerator is not None:
         return accelerator.autocast()
-    return torch.autocast("cuda", dtype=torch.bfloat16) if torch.cuda.is_available() else contextlib.nullcontext()
+    mp = getattr(opt, "mixed_precision", "bf16") if opt is not None else "bf16"
+    if mp not in ("bf16", "no"):
+        raise ValueError(f"mixed_precision must be 'bf16' or 'no' (fp16 autocast has no kernels here), got {mp!r}")
+    return torch.autocast("cuda", dtype=torch.bfloat16) if (mp == "bf16" and torch.cuda.is_available()) else contextlib.nullcontext()
 
 
 def _dev(model):
@@ -77,9 +83,7 @@ def compute_metrics(pred: torch.Tensor, gt: torch.Tensor, smooth: float = 1e-5) 
     return ops.mask_metrics(pred, gt, smooth)
 
 
-@_on_model_device
-@torch.no_grad()
-def save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, dataset_path="/data/dataset", pred_save_dir="predictions"):
+def _save_pred_masks(test_loader, model, opt, logger, accelerator, dataset_path, pred_save_dir, soft):
     from PIL import Image
     model.eval()
     main = _is_main(accelerator)
@@ -93,7 +97,7 @@ def save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, data
     dev = _dev(model)
     for batch_idx, batch in enumerate(test_loader, start=1):
         t0 = time.time()
-        with _autocast(accelerator):
+        with _autocast(accelerator, opt):
             pred_mask, _, _ = model(query_image_inputs=batch["query_img"].to(dev), support_image_inputs=batch["support_img"].to(dev),
                                     change_text_inputs=batch["text"].to(dev), support_mask_inputs=batch["support_mask"].to(dev),
                                     multimask_output=opt.multimask_output)
@@ -114,10 +118,11 @@ def save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, data
                 if gw <= 1 or gh <= 1:
                     logger.error(f"Invalid GT size {(gw, gh)} for {gt_path}, skipping sample")
                     continue
-                hard = ops.resize_binarize(pred[i:i + 1].contiguous(), gh, gw, 0.5)[0].cpu().numpy()
-                out_path = os.path.join(pred_save_path, f"{batch['pair_id'][i]}_{name}")
+                one = pred[i:i + 1].contiguous()
+                img = (ops.resize_gray(one, gh, gw) if soft else ops.resize_binarize(one, gh, gw, 0.5))[0].cpu().numpy()
+                out_path = os.path.join(pred_save_path, f"{_item(batch['pair_id'][i])}_{name}")
                 try:
-                    Image.fromarray(hard).save(out_path)
+                    Image.fromarray(img).save(out_path)
                 except Exception as e:                                        # noqa: BLE001
                     logger.error(f"Failed to save prediction mask {out_path}: {e}")
         meter.update(time.time() - t0)
@@ -130,12 +135,27 @@ def save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, data
         print(f"Predictions saved to {pred_save_path}, [Duration: {dur}]")
 
 
-_FIELDS = ["Id", "Query_img", "Query_mask", "Support_img", "Support_mask", "Text", "Compose", "Dataset", "Target", "query_cat",
-           "Dice", "MAE", "IoU", "mDice", "mIoU"]
+@_on_model_device
+@torch.no_grad()
+def save_hard_pred_masks(test_loader, model, opt, logger, accelerator=None, dataset_path="/data/dataset", pred_save_dir="predictions"):
+    """ref: utils/vailder.py:368-510 - sigmoid -> min-max -> resize to the GT size -> > 0.5 -> uint8 * 255 -> PNG."""
+    _save_pred_masks(test_loader, model, opt, logger, accelerator, dataset_path, pred_save_dir, soft=False)
+
+
+@_on_model_device
+@torch.no_grad()
+def save_soft_pred_masks(test_loader, model, opt, logger, accelerator=None, dataset_path="/data/dataset", pred_save_dir="predictions"):
+    """ref: utils/vailder.py:513-656 - as save_hard_pred_masks, but the resized probabilities are kept as grayscale:
+    (pred * 255).astype(np.uint8) instead of the 0.5 threshold."""
+    _save_pred_masks(test_loader, model, opt, logger, accelerator, dataset_path, pred_save_dir, soft=True)
 
 
 def _item(v):
     return v.item() if torch.is_tensor(v) else v
+
+
+_FIELDS = ["Id", "Query_img", "Query_mask", "Support_img", "Support_mask", "Text", "Compose", "Dataset", "Target", "query_cat",
+           "Dice", "MAE", "IoU", "mDice", "mIoU"]
 
 
 @_on_model_device
@@ -155,7 +175,7 @@ def val_metric(test_loader, model, opt, logger, accelerator=None, output_csv_nam
     t_epoch = time.time()
     for batch in test_loader:
         gt = batch["query_mask"].to(dev).float()
-        with _autocast(accelerator):
+        with _autocast(accelerator, opt):
             pred_mask, _, _ = model(query_image_inputs=batch["query_img"].to(dev), support_image_inputs=batch["support_img"].to(dev),
                                     change_text_inputs=batch["text"].to(dev), support_mask_inputs=batch["support_mask"].to(dev),
                                     multimask_output=opt.multimask_output)

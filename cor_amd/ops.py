@@ -399,6 +399,17 @@ def resize_binarize(prob, OH, OW, threshold=0.5):
     return out
 
 
+def resize_gray(prob, OH, OW):
+    """[B,1,H,W] probabilities -> uint8 [B,OH,OW] = (resized * 255) truncated (cv2.INTER_LINEAR semantics, utils/vailder.py:615-621)."""
+    _dev(prob)
+    assert prob.dtype == torch.float32 and prob.is_contiguous()
+    B, H, W = prob.shape[0], prob.shape[-2], prob.shape[-1]
+    assert prob.numel() == B * H * W
+    out = torch.empty((B, OH, OW), dtype=torch.uint8, device=prob.device)
+    nat.check(_lib().cor_resize_gray(prob.data_ptr(), out.data_ptr(), B, H, W, OH, OW, _s()), "cor_resize_gray")
+    return out
+
+
 def mask_metrics(pred, gt, smooth=1e-5):
     """per-sample [dice, mae, iou, mdice, miou] (utils/trainer_v3_g.py:381-443). pred, gt: [B,...] fp32 of equal shape."""
     _dev(pred, gt)

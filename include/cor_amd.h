@@ -184,6 +184,10 @@ int cor_mask_prob_minmax(const float* logits, float* out, int B, int HW, void* s
  * (> threshold) ? 255 : 0 as uint8. ref: utils/vailder.py:459-473. */
 int cor_resize_binarize(const float* prob, unsigned char* out, int B, int H, int W, int OH, int OW, float threshold, void* stream);
 
+/* The same resize, then (v * 255) truncated to uint8: the soft (grayscale) mask of save_soft_pred_masks.
+ * ref: utils/vailder.py:513-656 (:615-621: cv2.resize INTER_LINEAR, (pred * 255).astype(np.uint8)). */
+int cor_resize_gray(const float* prob, unsigned char* out, int B, int H, int W, int OH, int OW, void* stream);
+
 /* out[b] = {dice, mae, iou, mdice, miou} of a soft prediction against the ground truth, [B,HW] each.
  * ref: utils/trainer_v3_g.py:381-443 (compute_dice / compute_mae / compute_iou / compute_mdice / compute_miou). */
 int cor_mask_metrics(const float* pred, const float* gt, float* out, int B, int HW, float smooth, void* stream);
