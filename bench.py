@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=0, help="1: support branch on a second HIP stream (+4.5 % end to end; inflates per-kernel timings)")
     ap.add_argument("--host-inputs", type=int, default=0, help="1: the batch starts in pinned host memory and is copied H2D inside every step "
-                    "(PCIe-inclusive rate for DESIGN.md; never the headline value)")
+                    "on a second stream, double-buffered (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
     return ap.parse_args()
 
@@ -137,9 +137,16 @@ def main():
     shard = retrieval.GalleryShard(rows_all[lo:hi].to(dev), offset=lo, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
 
     host_batch = {k: v.cpu().pin_memory() for k, v in batch.items()} if args.host_inputs else None
+    h2d = utils.DoubleBufferedH2D(batch, dev) if args.host_inputs else None     # copy of batch i+1 under the forward of batch i
+    if h2d is not None:
+        h2d.stage(host_batch)
 
     def step():
-        b = {k: v.to(dev, non_blocking=True) for k, v in host_batch.items()} if host_batch is not None else batch
+        if h2d is not None:
+            b = h2d.take()
+            h2d.stage(host_batch)                      # next step's inputs start crossing PCIe now, on the copy stream
+        else:
+            b = batch
         masks, emb, feat = model(**b, multimask_output=True)
         return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B)    # results on rank 0 (merged once)
 

@@ -51,3 +51,39 @@ def synthetic_batch(B: int, device, seed: int = 0, vocab: int = 32000):
         mask[b, 0, y0:y0 + h, x0:x0 + w] = 1.0
     return dict(query_image_inputs=q.to(device), support_image_inputs=s.to(device), change_text_inputs=text.to(device),
                 support_mask_inputs=mask.to(device))
+
+
+class DoubleBufferedH2D:
+    """Host -> device staging of batch dicts on a second HIP stream, two resident device buffer sets: the copy of batch i+1 runs
+    under the forward of batch i (a 32-triplet batch is 477 MB of fp32 images and masks: ~9.6 ms over PCIe Gen5, 18 % of a step when
+    it is serialised with the compute). Usage: `stage(host_batch)` as early as possible, `batch = take()` when it is needed."""
+
+    def __init__(self, example: dict, device):
+        self.dev = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.bufs = [{k: torch.empty(v.shape, dtype=v.dtype, device=self.dev) for k, v in example.items()} for _ in range(2)]
+        self.ready = [None, None]            # event: copy into set i finished (recorded on the copy stream)
+        self.free = [None, None]             # event: the consumer is done with set i (recorded on its stream by take() of the NEXT batch)
+        self.n_staged = self.n_taken = 0
+
+    def stage(self, host_batch: dict):
+        i = self.n_staged % 2
+        with torch.cuda.stream(self.copy_stream):
+            if self.free[i] is not None:
+                self.copy_stream.wait_event(self.free[i])
+            for k, v in host_batch.items():
+                self.bufs[i][k].copy_(v, non_blocking=True)          # pinned host memory -> async DMA
+            ev = torch.cuda.Event(); ev.record(self.copy_stream)
+        self.ready[i] = ev
+        self.n_staged += 1
+
+    def take(self) -> dict:
+        assert self.n_taken < self.n_staged, "take() without a staged batch"
+        i = self.n_taken % 2
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.ready[i])
+        if self.n_taken > 0:                 # everything enqueued so far on the consumer stream used the OTHER set: it is free after this point
+            ev = torch.cuda.Event(); ev.record(cur)
+            self.free[1 - i] = ev
+        self.n_taken += 1
+        return self.bufs[i]

@@ -1032,6 +1032,33 @@ def test_gallery_builder_and_checkpoint_loader(tmp_path):
     retrieval.save_gallery(str(tmp_path / "gal"), rows.to(torch.float16), world=2)
     sh = retrieval.load_gallery_shard(str(tmp_path / "gal"), 1, DEV)
     assert sh.offset == 1 and len(sh) == 1 and torch.equal(sh.rows.cpu(), rows[1:2].to(torch.float16).cpu())
+    # the same builder fed from the reference's CSV schema (utils/dataloader.py:244-369): files decoded on the host, Pillow-exact
+    # resize on the GPU (cor_amd.dataloader.gallery_batches); rows with Compose != 0 are dropped
+    import csv as _csv
+    from PIL import Image
+    from cor_amd import dataloader
+    from oracle import preprocess as OP
+    rng = np.random.default_rng(63)
+    root = tmp_path / "data"
+    (root / "ds" / "image").mkdir(parents=True); (root / "ds" / "mask" / "dog").mkdir(parents=True)
+    recs = []
+    for i, (w, h) in enumerate([(300, 220), (180, 240), (256, 256)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(root / "ds" / "image" / f"q{i}.png")
+        mk = np.zeros((h, w), np.uint8); mk[h // 5: h // 2, w // 4: w // 2] = 255
+        Image.fromarray(mk).save(root / "ds" / "mask" / "dog" / f"m{i}.png")
+        recs.append(dict(Id=i, Query_img=f"q{i}.png", Query_mask=f"m{i}.png", Support_img="x.png", Support_mask="x.png", Text="t", Compose=int(i == 1),
+                         Dataset="ds", Target="dog", query_cat=0))
+    with open(tmp_path / "gal.csv", "w", newline="") as f:
+        wr = _csv.DictWriter(f, fieldnames=dataloader.CSV_COLUMNS); wr.writeheader(); wr.writerows(recs)
+    rows2 = retrieval.build_gallery(model, dataloader.gallery_batches(str(tmp_path / "gal.csv"), str(root), batch_size=2, device=DEV), dtype=torch.float32)
+    assert rows2.shape == (2, 256)                                                 # the Compose == 1 row is not a gallery entry
+    keep = [0, 2]
+    qi = torch.stack([torch.from_numpy(OP.to_tensor_normalize(OP.resize_bilinear_u8(np.asarray(Image.open(root / "ds" / "image" / f"q{i}.png").convert("RGB")), 1024, 1024),
+                                                              OP.IMAGENET_MEAN, OP.IMAGENET_STD)) for i in keep])
+    mi = torch.stack([torch.from_numpy(OP.to_tensor_normalize(OP.resize_bilinear_u8(np.asarray(Image.open(root / "ds" / "mask" / "dog" / f"m{i}.png").convert("L")), 1024, 1024),
+                                                              None, None)) for i in keep])
+    ref2 = oret.region_embedding(osam.image_encoder(sd, qi, dict(model.image_encoder.cfg)), mi)[:, 0]
+    report("gallery_rows_from_csv_vs_oracle", rows2, ref2, 1e-3, 1e-4)
 
 
 # ======================================================================================================

@@ -27,10 +27,21 @@ for Bq, Ng, k, dt in SHAPES:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); ops.similarity_topk(Q, G, k, flags=flags); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
-    t = sorted(ts[1:])[len(ts[1:]) // 2] * 1e-3          # median of the warm calls
+    t = sorted(ts[1:])[len(ts[1:]) // 2] * 1e-3          # median of the warm calls, each timed alone (includes the host's launch latency
+    # of the first kernel: the GPU is idle when the call starts). In the model step the stream is busy, so the figure that counts
+    # is the device time per call when calls are enqueued back to back:
+    NB = 8
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(NB):
+        ops.similarity_topk(Q, G, k, flags=flags)
+    e1.record(); e1.synchronize()
+    tb = e0.elapsed_time(e1) / NB * 1e-3
     fl = 2.0 * Bq * Ng * 256
     gbytes = G.numel() * G.element_size()
     peak = 2500.0 if dt != torch.float32 else 157.3
-    print(json.dumps(dict(Bq=Bq, Ng=Ng, k=k, dtype=str(dt), us_median=t * 1e6, us_min=min(ts[1:]) * 1e3, tflops=fl / t / 1e12,
-                          roofline=dict(bound="mfma" if Bq >= 400 else "hbm", achieved=fl / t / 1e12, peak=peak, unit="TFLOP/s", frac=fl / t / 1e12 / peak,
-                                        gallery_GBps=gbytes / t / 1e9, hbm_frac=gbytes / t / 8e12, algorithmic_bytes=gbytes + Bq * 1024))), flush=True)
+    print(json.dumps(dict(Bq=Bq, Ng=Ng, k=k, dtype=str(dt), us_back_to_back=tb * 1e6, us_single_median=t * 1e6, us_single_min=min(ts[1:]) * 1e3,
+                          tflops=fl / tb / 1e12,
+                          roofline=dict(bound="mfma" if Bq >= 400 else "hbm", achieved=fl / tb / 1e12, peak=peak, unit="TFLOP/s", frac=fl / tb / 1e12 / peak,
+                                        gallery_GBps=gbytes / tb / 1e9, hbm_frac=gbytes / tb / 8e12, algorithmic_bytes=gbytes + Bq * 1024,
+                                        note="whole call (prep + sample scan + tau + full scan + final selection), calls enqueued back to back"))), flush=True)
