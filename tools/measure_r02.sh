@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-2 measurement pass on the GPU box (one gpurun call): bench, rocprof kernel stats, PMC traffic (separate passes),
+# similarity / attention / GEMM micro-benchmarks, race screen. Outputs under gpurun_out/m/ ; copy the summaries to profiles/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/m; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+timeout -k 10 300 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || exit 1
+echo "bench done"; cut -c1-200 $O/bench.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_bench.json 2>/dev/null || exit 1
+echo "kernel trace done"
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_bench_$C -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_sim_$C -- python3 $R/tools/sim_bench.py 1m 4 > /dev/null 2>&1 || exit 1
+done
+echo "pmc done"
+cd $R
+python3 tools/pmc_traffic.py $O/pmc_bench_FETCH_SIZE $O/pmc_bench_WRITE_SIZE $O/pmc_traffic.json > /dev/null || exit 1
+python3 tools/pmc_traffic.py $O/pmc_sim_FETCH_SIZE $O/pmc_sim_WRITE_SIZE $O/sim_pmc_traffic.json "sim_scan<unsigned short, 2, false>" > /dev/null || exit 1
+timeout -k 10 200 python3 tools/sim_bench.py > $O/sim_bench.jsonl 2>/dev/null || exit 1
+cd /tmp; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sim -- python3 $R/tools/sim_bench.py 1m 6 > /dev/null 2>&1 || exit 1; cd $R
+timeout -k 10 200 python3 tools/attn_bench.py 32 > $O/attn_bench.jsonl 2>/dev/null || exit 1
+timeout -k 10 200 python3 tools/gemm_shapes.py > $O/gemm_shapes.jsonl 2>/dev/null || exit 1
+echo "micro benches done"
+timeout -k 10 300 python3 bench.py --sam sam_large --siglip ViT-L-16-SigLIP-384 --batch 64 --no-cpu-baseline > $O/bench_L.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 bench.py --dtype f32 --batch 8 --no-cpu-baseline > $O/bench_f32.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 bench.py --host-inputs 1 --no-cpu-baseline > $O/bench_host.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 bench.py --overlap 1 --no-cpu-baseline > $O/bench_overlap.json 2>/dev/null || exit 1
+echo "other configs done"
+timeout -k 10 400 python3 tools/race_screen.py 20 > $O/race_screen.txt 2>&1; echo "race rc=$?"; tail -2 $O/race_screen.txt
