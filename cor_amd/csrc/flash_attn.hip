@@ -471,11 +471,17 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 //     had one iteration, about its own global-load latency); one counted wait and one barrier per iteration.
 // LDS = 48 KiB rings + 32 KiB row-bias tables = 80 KiB: two blocks per CU. Tile -1 is a zero V tile with P = 0; the last
 // iteration's S(nt) comes from a stale K tile and is dropped.
-// PRE (q_prescale = scale * log2 e folded into q by the caller, a.scale_log2 == 1): the bias and the running reference are
-// folded INTO the score MFMA - S(t+1)'s accumulators start at  colbias[kw] + rowbias(t+1) - m  (one add per score) and the
-// MFMA result is already  x - m  in the log2 domain, so a score costs  add + max/2 + exp2 + cvt_pk/2  instead of
-// fma + max/2 + sub + exp2 + cvt_pk/2  (the softmax VALU, not the matrix pipe, bounds this kernel).
-template <typename TO, bool PRE>
+// FOLD (q_prescale = scale * log2 e folded into q by the caller, a.scale_log2 == 1): the softmax VALU, not the matrix pipe,
+// bounds this kernel (132 VALU + 32 quarter-rate exp2 against 20 MFMAs per tile and wave; matrix pipe 43 % busy), so the bias
+// and the running reference move ONTO the matrix pipe as extra k-steps of the score product:
+//     S(t)^T += I_perm . colbias^T            (4 MFMAs: the column bias as bf16 hi + lo halves against a permuted identity whose
+//                                              k-slot order is the accumulator's own row order: no exchange, 2^-17 relative)
+//     S(t)^T += ones . (rowbias(t) - m)^T     (1 MFMA per key block: three k-slots hold the bf16 hi / mid / lo parts)
+// and the MFMA result is already  x - m  in the log2 domain: a score costs  max + exp2 + cvt_pk/2  instead of
+// fma + max + sub + exp2 + cvt_pk/2  (-64 VALU, +10 MFMAs per tile). (Round 2 first tried the same fold through the
+// accumulator's start values - one add per score instead of two ops - which measured SLOWER: the adds sat on the MFMA's
+// critical path; an MFMA that starts from the inline constant 0 does not wait for VALU results.)
+template <typename TO, int FOLD>     // 0: fma form; 1: row bias - reference folded; 2: column bias folded too
 __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
@@ -541,6 +547,53 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       }
     }
   }
+  // FOLD operands. Column bias: B operand of k-step cc of key block kb = the lane's own wreg[kb][8 cc .. 8 cc + 7] (k-slot
+  // 8 h + i <-> accumulator row acc_row(8 cc + i, h)), split into a truncated bf16 hi half and the (exactly representable
+  // remainder's) bf16 lo half; the A operand is the matching permuted identity. Row bias: A = ones in k-slots 0..2.
+  uint4 twh[2][2], twl[2][2], idA[2], oneA;
+  if (FOLD == 2) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        unsigned hi[8]; float lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          hi[i] = __float_as_uint(wreg[kb][8 * cc + i]) & 0xffff0000u;
+          lo[i] = wreg[kb][8 * cc + i] - __uint_as_float(hi[i]);
+        }
+        twh[kb][cc] = make_uint4((hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3], (hi[4] >> 16) | hi[5], (hi[6] >> 16) | hi[7]);
+        twl[kb][cc] = pack8(lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]);
+      }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned e0 = r == acc_row(8 * cc + 2 * j, h) ? 0x3F80u : 0u, e1 = r == acc_row(8 * cc + 2 * j + 1, h) ? 0x3F800000u : 0u;
+        w[j] = e0 | e1;
+      }
+      idA[cc] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  if (FOLD) oneA = h == 0 ? make_uint4(0x3F803F80u, 0x00003F80u, 0, 0) : make_uint4(0, 0, 0, 0);
+  // (row bias - reference) as three bf16 parts in k-slots 0..2 (24 mantissa bits: the sum is exact in the fp32 accumulator)
+  auto th_operand = [&](float c) -> uint4 {
+    const unsigned c0 = __float_as_uint(c) & 0xffff0000u;
+    const float r1 = c - __uint_as_float(c0);
+    const unsigned c1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(c1);
+    return make_uint4((c0 >> 16) | c1, __float_as_uint(r2) >> 16, 0, 0);
+  };
+  // the bias k-steps of one key block: 4 column-bias MFMAs + 1 row-bias MFMA
+  auto fold_bias = [&](f32x16 acc, int kb, uint4 thB) -> f32x16 {
+#pragma unroll
+    for (int cc = 0; cc < (FOLD == 2 ? 2 : 0); ++cc) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, idA[cc]), __builtin_bit_cast(bf16x8, twh[kb][cc]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, idA[cc]), __builtin_bit_cast(bf16x8, twl[kb][cc]), acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oneA), __builtin_bit_cast(bf16x8, thB), acc, 0, 0, 0);
+  };
   __syncthreads();
 
   // ---- staging: LDS-DMA (global_load_lds_dwordx4), no registers. A tile is 64 rows x 128 B = 512 chunks of 16 B; thread tid
@@ -584,7 +637,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) lsum[e] = 0.f;
-  float m = PRE ? 0.f : -INFINITY;
+  float m = FOLD ? 0.f : -INFINITY;                    // FOLD: the reference is 0 until tile 0 has been seen
   const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
   uint4 pf[2][2];
 #pragma unroll
@@ -593,26 +646,39 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   // S(0)
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    const float c0 = PRE ? aux[r] : 0.f;                // row bias of key row 0 (reference m = 0 until tile 0 has been seen)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[kb][e] = PRE ? wreg[kb][e] + c0 : 0.f;
+    for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+    if (FOLD) s[kb] = fold_bias(s[kb], kb, th_operand(aux[r]));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint4 kf = *(const uint4*)(Kring + kb * 32 * 128 + kch[c]);
       s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
     }
   }
+  if (FOLD) {                                           // the reference starts at tile 0's maximum (O = l = 0: nothing to rescale)
+    float m0 = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m0 = fmaxf(m0, FOLD == 1 ? s[kb][e] + wreg[kb][e] : s[kb][e]);
+    m = fmaxf(m0, other_half(m0));
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kb][e] -= m;
+  }
   __syncthreads();                                      // every wave is done with K tile 0 before iteration 0 refills its slot
 
   int c3 = 0;                                           // t % 3
-#pragma unroll 1
-  for (int t = 0; t < nt; ++t) {
+  // one key tile; S(t) arrives in `s`, S(t+1) leaves in `sn`. FOLD consumes the raw MFMA result in the NEXT iteration, so the
+  // loop below runs two tiles per trip with the two register sets swapping roles (a single-tile loop copied 32 registers per tile)
+  auto tile_step = [&](const int t, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
     const int c3p1 = c3 == 2 ? 0 : c3 + 1, c3p2 = c3 == 0 ? 2 : c3 - 1;      // (t+1) % 3, (t+2) % 3 = (t-1) % 3
     issue_k(t + 3, c3);                                 // over K(t), last read in iteration t-1
     issue_v(t + 1, c3p1);                               // over V(t-2), last read in iteration t-1
     const char* Vs = Vring + c3p2 * TILE_B;             // V(t-1)
     const char* Ks = Kring + c3p1 * TILE_B;             // K(t+1)
-    const float rh = PRE ? aux[min(t + 1, nt - 1) * 32 + r] : aux[t * 32 + r];   // PRE: row bias of the NEXT tile (folded into S(t+1))
+    const float rh = FOLD ? aux[min(t + 1, nt - 1) * 32 + r] : aux[t * 32 + r];   // FOLD: row bias of the NEXT tile (folded into S(t+1))
     // ---- phase A: PV(t-1) and row-sum MFMAs beside (scale + bias +) max of S(t)
     uint4 vf[8];
 #pragma unroll
@@ -632,22 +698,36 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     float mloc = -INFINITY;
-    f32x16 sn[2];
-    if (PRE) {
-      // max of S(t) and the start values of S(t+1) (column bias + next row bias - CURRENT reference; corrected below in the
-      // rare case that the reference moves), all beside the PV MFMAs
-      const float cinit = rh - m;
+    int imax = 0;
+    if (FOLD == 1) {
+      // S(t) is x - m short of the column bias: one add per score, then only max(0, tile maximum) is needed
+      float pmax = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          mloc = fmaxf(mloc, fmaxf(s[kb][e], s[kb][e + 1]));
-          sn[kb][e] = wreg[kb][e] + cinit; sn[kb][e + 1] = wreg[kb][e + 1] + cinit;
+          const float x0 = s[kb][e] + wreg[kb][e], x1 = s[kb][e + 1] + wreg[kb][e + 1];
+          s[kb][e] = x0; s[kb][e + 1] = x1;
+          pmax = fmaxf(pmax, fmaxf(x0, x1));
         }
+      imax = __float_as_int(pmax);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU (16 max + 32 add for 12 MFMAs)
+      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+    } else if (FOLD == 2) {
+      // S(t) is already x - m: only max(0, tile maximum) is left to the VALU, and for that the INTEGER maximum of the float
+      // bit patterns is exact (any positive float beats every negative one and positives order like their bits; a float max
+      // of raw MFMA results would cost a canonicalising v_max per operand)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) imax = max(imax, max(__float_as_int(s[kb][e]), __float_as_int(s[kb][e + 1])));
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 2 VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     } else {
 #pragma unroll
@@ -666,17 +746,18 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     float msub = 0.f;
-    if (PRE) {
-      mloc = fmaxf(mloc, other_half(mloc));             // tile maximum of x - m
-      // reference update: always after tile 0 (m = its maximum), later only when a tile maximum exceeds it by 2^8 (lazy rescale)
-      if (t == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
-        const float d = t == 0 ? mloc : fmaxf(mloc, 0.f);
+    if (FOLD) {
+      // reference update only when a tile maximum exceeds it by 2^8 (lazy rescale); S(t+1) is issued below, after the update,
+      // so its row-bias operand carries the new reference
+      if (__builtin_amdgcn_ballot_w64(imax > 0x41000000) != 0) {               // some x - m > 8.0f
+        mloc = __int_as_float(imax);
+        const float d = fmaxf(mloc, other_half(mloc)); // >= 0
         const float alpha = __builtin_amdgcn_exp2f(-d);
         m += d;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { s[kb][e] -= d; sn[kb][e] -= d; }
+          for (int e = 0; e < 16; ++e) s[kb][e] -= d;
         lsum[0] *= alpha;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -701,37 +782,51 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     uint4 kf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) kf[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
-    if (!PRE) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
-    }
+      for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
+    uint4 thB = make_uint4(0, 0, 0, 0);
+    if (FOLD) thB = th_operand(rh - m);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), sn[kb], 0, 0, 0);
+      if (FOLD) sn[kb] = fold_bias(sn[kb], kb, thB);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 p;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(PRE ? s[kb][e] : s[kb][e] - msub);
+      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(FOLD ? s[kb][e] : s[kb][e] - msub);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                       // 1 MFMA : 11 (PRE: 7) VALU
+    for (int i = 0; i < (FOLD == 2 ? 18 : FOLD == 1 ? 10 : 8); ++i) {         // 1 MFMA : 11 (FOLD 1: 6, 2: 3) VALU
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 7 : 11, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, FOLD == 2 ? 3 : FOLD == 1 ? 6 : 11, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    s[0] = sn[0]; s[1] = sn[1];
     c3 = c3p1;
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 stay in flight
     __syncthreads();
+  };
+  f32x16 s2[2];
+  if (FOLD == 2) {
+#pragma unroll 1
+    for (int t = 0; t < nt; t += 2) {                   // nt = 64 (the host checks grid == 64)
+      tile_step(t, s, s2);
+      tile_step(t + 1, s2, s);
+    }
+  } else {
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+      tile_step(t, s, s2);
+      s[0] = s2[0]; s[1] = s2[1];
+    }
   }
   // PV(nt-1) and its row sums
   {
@@ -998,24 +1093,23 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO, bool PRE>
+template <typename TO, int FOLD>
 int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO, PRE>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, 128);
-  hipLaunchKernelGGL((flash_global_pipe<TO, PRE>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
 }
-// PRE (bias / reference folded into the score accumulator) is NOT the default: measured 2.68-2.78 ms against 2.29-2.44 ms for
-// the fma form on the same boxes at B = 32 (tools/attn_bench.py) although it issues 32 fewer VALU per tile - in this kernel time
-// does not follow the VALU count (see the header); it stays selectable (variant 2) as the in-process A/B partner. The windowed
-// kernel (win_attn), whose blocks are short and VALU-bound, does gain from the same idea.
+// FOLD (bias and reference as extra k-steps of the score MFMA, see the kernel header) needs q pre-scaled by scale * log2 e
+// (a.scale_log2 == 1); raw-q callers get the fma form.
 template <typename TO>
-int launch_global_pipe(const FlashArgs& a, int nb, bool folded, hipStream_t s) {
-  return (folded && a.scale_log2 == 1.0f) ? launch_global_pipe_<TO, true>(a, nb, s) : launch_global_pipe_<TO, false>(a, nb, s);
+int launch_global_pipe(const FlashArgs& a, int nb, int fold, hipStream_t s) {
+  if (a.scale_log2 != 1.0f) fold = 0;
+  return fold == 2 ? launch_global_pipe_<TO, 2>(a, nb, s) : fold == 1 ? launch_global_pipe_<TO, 1>(a, nb, s) : launch_global_pipe_<TO, 0>(a, nb, s);
 }
 
 template <int MODE, typename TO, int HD = 64>
@@ -1041,8 +1135,11 @@ int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
 
 // `variant` (per call): 0 (default) = flash_global_pipe (global; software-pipelined over key tiles) / win_attn (windowed; one
 // 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>, the round-1 chain forms of the same arithmetic (kept as
-// the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py); 2 = global attention with the bias
-// folded into the score accumulator (needs q_prescale = scale * log2 e; measured slower, see launch_global_pipe).
+// the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py); 2 / 3 = global attention with the
+// column + row bias and the running reference (2) or the row bias and reference only (3) as extra k-steps of the score MFMA
+// (needs q_prescale = scale * log2 e). Measured at B = 32 (profiles/r02_attention_fold_ablation.jsonl): variant 0 2.29-2.39 ms,
+// variant 3 2.41-2.42 ms (-33 VALU, +2 MFMAs per tile: +1 %), variant 2 2.57-2.68 ms (-64 VALU, +10 MFMAs: +12 %), variant 1
+// 2.40-2.51 ms: the kernel's time does not follow its VALU count, so the default stays the fma form.
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -1072,9 +1169,10 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
-    if (variant == 0 || variant == 2) {
-      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, variant == 2, s);
-      if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, variant == 2, s);
+    if (variant == 0 || variant == 2 || variant == 3) {
+      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : 0;
+      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, fold, s);
+      if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, fold, s);
     }
     if (out_dtype == COR_BF16) return launch<1, bf16_t>(a, B, s);
     if (out_dtype == COR_F32) return launch<1, float>(a, B, s);

@@ -378,7 +378,16 @@ def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
     o_p = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)
     o_p2 = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)
     assert torch.equal(o_p, o_p2)
-    o_f = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2)    # bias folded into the accumulator
+    o_f = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2)    # bias + reference as extra k-steps of the score MFMA
+    assert torch.equal(o_f, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2))
+    r_ff = report(f"global_attn_mfma_fold_vs_fma_form_B{B}_H{H}_amp{amp}", o_f, o_p if False else ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c),
+                  rtol=0, atol=(4e-2 if amp > 2 else 1e-2) * float(ref.abs().max()))
+    assert r_ff["rel_l2"] <= (1e-2 if amp > 2 else 2e-3), r_ff       # same operands: only the bias split (2^-17) and bf16-P rounding points differ
+    o_f1 = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=3)   # row bias - reference folded only
+    assert torch.equal(o_f1, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=3))
+    r_f1 = report(f"global_attn_rowbias_fold_vs_fma_form_B{B}_H{H}_amp{amp}", o_f1, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c),
+                  rtol=0, atol=(4e-2 if amp > 2 else 1e-2) * float(ref.abs().max()))
+    assert r_f1["rel_l2"] <= (1e-2 if amp > 2 else 2e-3), r_f1
     report(f"global_attn_prescaled_folded_B{B}_H{H}_amp{amp}", o_f, ref, rtol=8e-2 if amp > 2 else 2e-2, atol=(8e-2 if amp > 2 else 2e-2) * float(ref.abs().max()))
     tol = 8e-2 if amp > 2 else 2e-2
     r_p = report(f"global_attn_prescaled_B{B}_H{H}_amp{amp}", o_p, ref, rtol=tol, atol=tol * float(ref.abs().max()))
