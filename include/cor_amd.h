@@ -215,10 +215,14 @@ int cor_resample_cols_u8(const unsigned char* in, float* out_f32, unsigned char*
  * Q [Bq,C] fp32, G [Ng,C] in g_dtype (COR_F32 exact chain / COR_BF16 / COR_F16), C <= 256 and C % 16 == 0, k <= 32;
  * missing entries (Ng < k) come back as score -inf, index -1. workspace >= cor_topk_workspace_bytes(Bq,Ng,k).
  * The reference has no gallery/top-k code; the definition follows utils/loss_func.py:84 (cosine of unit vectors).
- * 16-bit shards of >= 32768 rows use threshold-and-append (a dense sample pass bounds each query's k-th best score,
- * the full pass appends the rare scores above it, exact selection over the candidates); if a query's candidate list
- * overflows (pathological score distributions) ALL its indices come back as -2: repeat the call with
- * flags = COR_TOPK_FORCE_LISTS (per-lane list kernels, always exact). `flags` is per call: no process-global state. */
+ * Scores are DEFINED as the fp32 fmaf chain of oracle/c/sim_chain.c (16-bit rows widened exactly), for every gallery dtype: the
+ * result is bit-identical to that CPU chain, scores and indices. fp32 shards run the chain kernel. 16-bit shards of >= 32768
+ * rows run threshold-and-append on the matrix cores (a strided sample pass bounds each query's k-th best score, the full MFMA
+ * pass appends the rare score records above the bound, the final pass re-scores a short list with the exact chain); if a
+ * query's candidate list overflows (pathological score distributions) its block falls back to an exact brute-force chain
+ * pass ON THE DEVICE (no host round trip). `flags` (per call, no process-global state): 0 = default;
+ * COR_TOPK_FORCE_LISTS = per-lane sorted-list kernels only; COR_TOPK_NO_FALLBACK = report an overflow as index -2 in every
+ * slot of the query instead of falling back (tests). */
 long cor_topk_workspace_bytes(int Bq, int Ng, int k);
 int cor_similarity_topk(const float* Q, const void* G, int g_dtype, int Bq, int Ng, int C, int k, long long g_offset,
                         float* out_scores, long long* out_idx, void* workspace, int flags, void* stream);
