@@ -15,6 +15,7 @@ F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4
 EINVAL, ENOSUPPORT = -1, -2
 TOPK_FORCE_LISTS, TOPK_NO_FALLBACK = 1, 2
+ORDER_REVERSE = 1 << 30    # cor_gemm cfg / cor_layernorm act / cor_sam_attention variant: walk the work from the last item to the first
 KERNEL_ROWLANE, KERNEL_FEWQ, KERNEL_FLASH_MFMA, KERNEL_FLASH_PIPELINED, KERNEL_WINDOW_BLOCK = 1, 2, 3, 4, 5
 import numpy as _np
 Q_PRESCALE_HD64 = float(_np.float32(0.125) * _np.float32(1.4426950408889634))   # scale * log2(e) for head_dim 64, as a float32

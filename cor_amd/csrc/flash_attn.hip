@@ -32,6 +32,7 @@ struct FlashArgs {
   const bf16_t* pad_row; const float* rel_h; const float* rel_w;
   int grid, S, nW, d3;                                  // SAM: image grid, rel-pos size, windows per side, 3*H*64
   int nqt;                                              // query tiles (128 queries) per (batch, head)
+  int rev;                                              // 1: work items from the last to the first (COR_ORDER_REVERSE)
 };
 
 constexpr int KT = 64;                       // keys per tile
@@ -145,7 +146,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
   const int r = lane & 31, h = lane >> 5;
   // XCD-aware placement: the nqt query tiles of one (batch, head) re-read the same K/V (1 MiB at 4096 keys); hand each
   // XCD (blocks with equal id % 8) a contiguous run of work items so those re-reads hit ITS L2 instead of HBM/MALL.
-  const int wi_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int wi0_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int wi_ = a.rev ? (int)gridDim.x - 1 - wi0_ : wi0_;
   const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
   const int head = hb_ % a.H, bz = hb_ / a.H;
   const int S = a.S;
@@ -487,7 +489,8 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wi_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int wi0_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int wi_ = a.rev ? (int)gridDim.x - 1 - wi0_ : wi0_;
   const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
   const int head = hb_ % a.H, b = hb_ / a.H;
   const int S = a.S;                                   // 64
@@ -882,7 +885,8 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.x % a.H, win = blockIdx.x / a.H;
+  const int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int head = bid % a.H, win = bid / a.H;
   const int nw2 = a.nW * a.nW, b = win / nw2, wi = win - b * nw2, wy = wi / a.nW, wx = wi - wy * a.nW;
   const int g2 = a.grid * a.grid;
   char* Kt = smem; char* Vt = smem + WIN_KV;
@@ -1159,9 +1163,11 @@ int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, lon
 int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pad_row, const float* rel_h, const float* rel_w, int B,
                        int H, int hd, int grid, int window, float q_prescale, int variant, hipStream_t s) {
   if (hd != 64 && hd != 80) return COR_ENOSUPPORT;     // SAM-B/L: 64, SAM-H: 80
+  const int rev = (variant & COR_ORDER_REVERSE) ? 1 : 0;
+  variant &= ~COR_ORDER_REVERSE;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
-  a.q = (const bf16_t*)qkv; a.o = out; a.H = H;
+  a.q = (const bf16_t*)qkv; a.o = out; a.H = H; a.rev = rev;
   a.scale_log2 = LOG2E / sqrtf((float)hd) / q_prescale; a.tbl_scale = LOG2E / q_prescale;
   if (hd == 64 && fabsf(a.scale_log2 - 1.0f) < 1e-6f) { a.scale_log2 = 1.0f; a.tbl_scale = 8.0f; }   // q_prescale = 0.125 * log2(e): exact constants
   a.pad_row = (const bf16_t*)pad_row; a.rel_h = rel_h; a.rel_w = rel_w; a.grid = grid; a.d3 = 3 * H * hd;

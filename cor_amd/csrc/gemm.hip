@@ -37,6 +37,7 @@ struct GemmArgs {
   int group_m;         // tile order: M-panels per band (L2 blocking)
   int dbg;             // timing-only ablation knobs (tools/gemm_ksweep.py): 1 no C stores, 2 no epilogue, 4 no MFMA
   int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
+  int rev;             // 1: walk the tile order backwards (COR_ORDER_REVERSE: start where the producer of A finished)
 };
 
 template <typename TA> struct Mfma;
@@ -174,7 +175,8 @@ gemm_tile(const GemmArgs g) {   // <= 256 VGPR+AGPR (2 waves per SIMD) except th
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int swz0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int swz = g.rev ? (int)gridDim.x - 1 - swz0 : swz0;
   // Grouped tile order inside an XCD's contiguous chunk: bands of GM row-panels, column-major inside a band, so the ~64
   // blocks resident on an XCD cover GM A-panels x (64/GM) W-panels whose ~3 MB fit the 4 MiB L2 (row-major order made
   // every block of a wide-N GEMM miss on W: 14x over-fetch measured with FETCH_SIZE on the N=3072 MLP GEMM).
@@ -476,7 +478,8 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 
   unsigned oa[4], ob[4];                            // per-lane byte offsets of the four 64-row blocks (rows clamped at the edge)
   int m0 = 0, n0 = 0;
-  auto set_tile = [&](int L) {
+  auto set_tile = [&](int Lf) {
+    const int L = g.rev ? g.tm * g.tn - 1 - Lf : Lf;
     const int band = L / (GM * g.tn), rem = L - band * (GM * g.tn);
     const int gm_eff = min(GM, g.tm - band * GM);
     m0 = (band * GM + rem % gm_eff) * BM; n0 = (rem / gm_eff) * BN;
@@ -740,7 +743,7 @@ template <typename TA, typename TO>
 int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                 const float* bias, int act, const float* col_scale, const float* residual, long ldr, int res_row_mod,
                 int cfg_arg, hipStream_t s) {
-  const int g_gemm_cfg = cfg_arg & 0xff, g_gemm_dbg = cfg_arg >> 8;
+  const int g_gemm_cfg = cfg_arg & 0xff, g_gemm_dbg = (cfg_arg & ~COR_ORDER_REVERSE) >> 8;
   const long esz = sizeof(TA);
   const bool fast = (K * esz) % 16 == 0 && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0 &&
                     ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0);
@@ -755,7 +758,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
   g.M = M; g.N = N; g.Kb = (int)(K * esz);
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
-  g.dbg = g_gemm_dbg;
+  g.dbg = g_gemm_dbg; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
   g.group_m = (g_gemm_dbg >> 4) ? (g_gemm_dbg >> 4) : 8;
   const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   g.vec_epi = (N % 4 == 0) && (N >= 8) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&

@@ -8,9 +8,9 @@ namespace {
 // ---------------------------------------------------------------- LayerNorm: one wave per row, row cached in registers
 template <typename TI, typename TO, int MAXV>   // MAXV = ceil(C / 256) vectors of 4 per lane
 __global__ void __launch_bounds__(256) layernorm_kernel(const TI* x, TO* y, const float* w, const float* b, int rows, int C,
-                                                        float eps, int act) {
+                                                        float eps, int act, int rev) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = (rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const TI* xr = x + (long)row * C;
   const int nv = C >> 2;          // C % 4 == 0 (checked by the launcher)
@@ -47,10 +47,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* x, TO* y, cons
 }
 
 template <typename TI, typename TO>
-int launch_ln(const void* x, void* y, const float* w, const float* b, int rows, int C, float eps, int act, hipStream_t s) {
+int launch_ln(const void* x, void* y, const float* w, const float* b, int rows, int C, float eps, int act, int rev, hipStream_t s) {
   const dim3 grid(cdiv(rows, 4)), block(256);
   const int nv = cdiv(C, 256);
-#define LN_CASE(MV) hipLaunchKernelGGL((layernorm_kernel<TI, TO, MV>), grid, block, 0, s, (const TI*)x, (TO*)y, w, b, rows, C, eps, act)
+#define LN_CASE(MV) hipLaunchKernelGGL((layernorm_kernel<TI, TO, MV>), grid, block, 0, s, (const TI*)x, (TO*)y, w, b, rows, C, eps, act, rev)
   if (nv <= 1) LN_CASE(1);
   else if (nv <= 2) LN_CASE(2);
   else if (nv <= 3) LN_CASE(3);
@@ -238,7 +238,9 @@ extern "C" int cor_version(void) { return 1; }
 extern "C" int cor_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float* w, const float* b, int rows, int C,
                              float eps, int act, void* stream) {
   if (!x || !y || !w || !b || rows <= 0 || C <= 0 || (C & 3)) return COR_EINVAL;
-#define CALL(TI, TO) return launch_ln<TI, TO>(x, y, w, b, rows, C, eps, act, (hipStream_t)stream)
+  const int rev = (act & COR_ORDER_REVERSE) ? 1 : 0;   // rows from the last to the first (see COR_ORDER_REVERSE)
+  act &= ~COR_ORDER_REVERSE;
+#define CALL(TI, TO) return launch_ln<TI, TO>(x, y, w, b, rows, C, eps, act, rev, (hipStream_t)stream)
   DISPATCH2(x_dtype, y_dtype, CALL)
 #undef CALL
 }

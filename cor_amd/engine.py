@@ -188,13 +188,13 @@ def pack(sd: dict, scfg: dict, gcfg: dict, mask_pooling: str, T: torch.dtype) ->
 # =====================================================================================================
 # building blocks
 # =====================================================================================================
-def _lin(W, p, a, out_dtype, act=ACT_NONE, residual=None, col_scale=None, out=None):
+def _lin(W, p, a, out_dtype, act=ACT_NONE, residual=None, col_scale=None, out=None, reverse=False):
     return ops.gemm(a, W[p + "weight"], out_dtype=out_dtype, bias=W[p + "bias"], act=act, residual=residual,
-                    col_scale=col_scale, out=out)
+                    col_scale=col_scale, out=out, reverse=reverse)
 
 
-def _ln(W, p, x, eps, out_dtype, act=ACT_NONE):
-    return ops.layernorm(x, W[p + "weight"], W[p + "bias"], eps, out_dtype=out_dtype, act=act)
+def _ln(W, p, x, eps, out_dtype, act=ACT_NONE, reverse=False):
+    return ops.layernorm(x, W[p + "weight"], W[p + "bias"], eps, out_dtype=out_dtype, act=act, reverse=reverse)
 
 
 def _gelu(kind):
@@ -210,16 +210,20 @@ def sam_encoder(W, img, cfg, T, p="image_encoder."):
     x = ops.gemm(cols, W[p + "patch_embed.proj.weight"], out_dtype=F32, bias=W[p + "patch_embed.proj.bias"],
                  residual=W[p + "pos_embed"], res_row_mod=g * g)                        # :110-112
     del cols
+    # Work order along the chain: the GEMMs write their outputs from the first row panel to the last, so the kernels that
+    # consume a GEMM's output (LayerNorm over the 403 MB residual, attention over the 604 MB qkv) walk it from the LAST row to
+    # the first - they start on the ~200 MB the producer left in the 256 MB Infinity Cache and finish on the low rows, where
+    # the next GEMM starts (measured +0.5 ... +2.5 % end to end depending on the box, profiles/r02_work_order_ab.txt).
     for i in range(cfg["depth"]):
         b = f"{p}blocks.{i}."
         win = 0 if i in cfg["global_idx"] else cfg["window"]
-        h = _ln(W, b + "norm1.", x, 1e-6, T)                                              # :169
+        h = _ln(W, b + "norm1.", x, 1e-6, T, reverse=True)                                # :169
         qkv = _lin(W, b + "attn.qkv.", h, T)                                              # :229
         a = ops.sam_attention(qkv, W[b + "attn.pad_row"], W[b + "attn.rel_pos_h"], W[b + "attn.rel_pos_w"], B, H, g, win,
-                              q_prescale=W[b + "attn.q_prescale"])                          # :172-180,232-238
+                              q_prescale=W[b + "attn.q_prescale"], reverse=True)            # :172-180,232-238
         del qkv
         _lin(W, b + "attn.proj.", a, F32, residual=x, out=x)                              # :239,182
-        h = _ln(W, b + "norm2.", x, 1e-6, T)
+        h = _ln(W, b + "norm2.", x, 1e-6, T, reverse=True)
         m = _lin(W, b + "mlp.lin1.", h, T, act=ACT_GELU_ERF)                              # common.py:25-26
         _lin(W, b + "mlp.lin2.", m, F32, residual=x, out=x)                               # :183
         del h, a, m

@@ -67,8 +67,9 @@ def _f32vec(t, n, name):
     assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, f"{name}: need contiguous fp32[{n}]"
 
 
-def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual=None, res_row_mod=0, out=None, cfg=0):
-    """out[M,N] = residual + col_scale * act(a[M,K] @ w[N,K]^T + bias). cfg: per-call kernel choice (0 = automatic)."""
+def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual=None, res_row_mod=0, out=None, cfg=0, reverse=False):
+    """out[M,N] = residual + col_scale * act(a[M,K] @ w[N,K]^T + bias). cfg: per-call kernel choice (0 = automatic).
+    reverse: walk the tiles from the last row panel to the first (same result; see ORDER_REVERSE)."""
     _dev(a, w, bias, col_scale, residual, out)
     M, K, lda = _rows(a)
     N, K2, ldw = _rows(w)
@@ -88,7 +89,7 @@ def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     nat.check(_lib().cor_gemm(a.data_ptr(), lda, w.data_ptr(), ldw, _dt(a), out.data_ptr(), ldc, _dt(out), M, N, K,
-                              _p(bias), act, _p(col_scale), _p(residual), ldr, res_row_mod, int(cfg), _s()), "cor_gemm")
+                              _p(bias), act, _p(col_scale), _p(residual), ldr, res_row_mod, int(cfg) | (nat.ORDER_REVERSE if reverse else 0), _s()), "cor_gemm")
     if prof is not None:
         e1.record()
         nbytes = (M * K + N * K) * a.element_size() + M * N * out.element_size() + (M * N * 4 if residual is not None else 0)
@@ -96,7 +97,7 @@ def gemm(a, w, out_dtype=None, bias=None, act=ACT_NONE, col_scale=None, residual
     return out
 
 
-def layernorm(x, w, b, eps, out_dtype=None, act=ACT_NONE, out=None):
+def layernorm(x, w, b, eps, out_dtype=None, act=ACT_NONE, out=None, reverse=False):
     _dev(x, w, b, out)
     assert x.is_contiguous() and x.dim() == 2
     rows, C = x.shape
@@ -106,7 +107,7 @@ def layernorm(x, w, b, eps, out_dtype=None, act=ACT_NONE, out=None):
         out = torch.empty((rows, C), dtype=out_dtype or x.dtype, device=x.device)
     assert out.is_contiguous() and out.shape == x.shape
     nat.check(_lib().cor_layernorm(x.data_ptr(), _dt(x), out.data_ptr(), _dt(out), w.data_ptr(), b.data_ptr(), rows, C,
-                                   float(eps), act, _s()), "cor_layernorm")
+                                   float(eps), act | (nat.ORDER_REVERSE if reverse else 0), _s()), "cor_layernorm")
     return out
 
 
@@ -123,7 +124,7 @@ def attention(q, k, v, B, H, Tq, Tk, hd, scale, out_dtype=None):
     return out
 
 
-def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None, variant=0, q_prescale=1.0):
+def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None, variant=0, q_prescale=1.0, reverse=False):
     _dev(qkv, pad_row, rel_h, rel_w)
     hd = rel_h.shape[1]
     d = H * hd
@@ -135,7 +136,7 @@ def sam_attention(qkv, pad_row, rel_h, rel_w, B, H, grid, window, out_dtype=None
         assert pad_row is not None and pad_row.dtype == qkv.dtype and pad_row.is_contiguous() and pad_row.numel() == 3 * d
     out = torch.empty((B * grid * grid, d), dtype=out_dtype or qkv.dtype, device=qkv.device)
     nat.check(_lib().cor_sam_attention(qkv.data_ptr(), _dt(qkv), out.data_ptr(), _dt(out), _p(pad_row), rel_h.data_ptr(),
-                                       rel_w.data_ptr(), B, H, hd, grid, window, float(q_prescale), int(variant), _s()), "cor_sam_attention")
+                                       rel_w.data_ptr(), B, H, hd, grid, window, float(q_prescale), int(variant) | (nat.ORDER_REVERSE if reverse else 0), _s()), "cor_sam_attention")
     return out
 
 

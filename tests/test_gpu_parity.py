@@ -1226,3 +1226,35 @@ def test_full_size_batch_invariance_and_retrieval(sam_name, siglip_name, B, mode
     sb, ib = retrieval.GalleryShard(rows[5000:], 5000, gdt).search(q, 10)
     sm, im = retrieval.merge_topk_host([sa.cpu(), sb.cpu()], [ia.cpu(), ib.cpu()], 10)
     assert torch.equal(im, i_all.cpu()) and torch.equal(sm, s_all.cpu())
+
+
+def test_reverse_work_order_is_bit_identical():
+    """COR_ORDER_REVERSE (gemm cfg / layernorm act / sam_attention variant) only changes the order in which tiles, rows and
+    windows are visited: outputs must be bit-identical (persistent and 128x128 GEMM kernels, bf16 and fp32, in-place residual)."""
+    ops, _ = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for (M, N, K, T, TO) in ((131072 // 8, 768, 768, BF16, F32), (2048 + 77, 2304, 768, BF16, BF16), (1000, 300, 256, F32, F32), (70000, 768, 3072, BF16, F32)):
+        a = torch.randn((M, K), generator=g, device=DEV).to(T)
+        w = (torch.randn((N, K), generator=g, device=DEV) * 0.05).to(T)
+        bias = torch.randn((N,), generator=g, device=DEV)
+        res = torch.randn((M, N), generator=g, device=DEV) if TO == F32 else None
+        o0 = ops.gemm(a, w, out_dtype=TO, bias=bias, residual=res)
+        o1 = ops.gemm(a, w, out_dtype=TO, bias=bias, residual=res, reverse=True)
+        assert torch.equal(o0, o1), (M, N, K)
+        if res is not None:                                             # in place, as the encoder runs it
+            x0, x1 = res.clone(), res.clone()
+            ops.gemm(a, w, out_dtype=TO, bias=bias, residual=x0, out=x0)
+            ops.gemm(a, w, out_dtype=TO, bias=bias, residual=x1, out=x1, reverse=True)
+            assert torch.equal(x0, x1) and torch.equal(x0, o0)
+    x = torch.randn((4099, 768), generator=g, device=DEV)
+    wv, bv = torch.randn((768,), generator=g, device=DEV), torch.randn((768,), generator=g, device=DEV)
+    assert torch.equal(ops.layernorm(x, wv, bv, 1e-6, out_dtype=BF16), ops.layernorm(x, wv, bv, 1e-6, out_dtype=BF16, reverse=True))
+    B, H = 2, 12
+    qkv = torch.randn((B * 4096, 3 * H * 64), generator=g, device=DEV).to(BF16)
+    pad = torch.randn((3 * H * 64,), generator=g, device=DEV).to(BF16)
+    for win, S in ((0, 64), (14, 14)):
+        rh = torch.randn((2 * S - 1, 64), generator=g, device=DEV) * 0.3
+        rw = torch.randn((2 * S - 1, 64), generator=g, device=DEV) * 0.3
+        for variant in (0, 1):
+            assert torch.equal(ops.sam_attention(qkv, pad, rh, rw, B, H, 64, win, variant=variant),
+                               ops.sam_attention(qkv, pad, rh, rw, B, H, 64, win, variant=variant, reverse=True)), (win, variant)
