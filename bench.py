@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=0, help="1: support branch on a second HIP stream (+4.5 % end to end; inflates per-kernel timings)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the forward as ONE captured hipGraph (model.capture); no per-launch "
+                    "GEMM events exist then, so `roofline` is reported as unmeasured - matters at small --batch, not at 32")
     ap.add_argument("--host-inputs", type=int, default=0, help="1: the batch starts in pinned host memory and is copied H2D inside every step "
                     "on a second stream, double-buffered (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
@@ -141,13 +143,15 @@ def main():
     if h2d is not None:
         h2d.stage(host_batch)
 
+    graphed = model.capture(**batch, multimask_output=True) if args.graph else None
+
     def step():
         if h2d is not None:
             b = h2d.take()
             h2d.stage(host_batch)                      # next step's inputs start crossing PCIe now, on the copy stream
         else:
             b = batch
-        masks, emb, feat = model(**b, multimask_output=True)
+        masks, emb, feat = graphed(**b) if graphed is not None else model(**b, multimask_output=True)
         return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B)    # results on rank 0 (merged once)
 
     def barrier():
@@ -203,6 +207,9 @@ def main():
                          "algorithmic_bytes_per_launch": gemm_bytes / max(n_launch, 1), "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
         }
+        if args.graph:
+            res["roofline"].update(achieved=None, frac=None, note="graph replay: no per-launch events (run without --graph for the roofline)")
+            res["config"]["launch"] = "hipGraph replay of the forward"
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], rec = cpu_baseline_and_recall(args, model, batch, rows_all, dev)
             res["recall_at_1"] = rec["recall_at_1"]

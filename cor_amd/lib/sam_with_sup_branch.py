@@ -84,6 +84,19 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
                                   change_text_inputs, support_mask_inputs, multimask_output)
 
     @torch.no_grad()
+    def capture(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, multimask_output=True,
+                warmup=2):
+        """Capture forward() for THESE input shapes into a hipGraph and return a `GraphedForward`: calling it copies new
+        inputs into the captured buffers and replays the ~600 kernel launches of a forward as ONE graph launch (the eager
+        path pays one ctypes call + one launch per kernel: launch-bound at small batch). The example inputs are only read
+        during warm-up and capture; the packed weights are captured by address (re-capture after changing parameters)."""
+        if self.training:
+            raise RuntimeError("cor_amd implements the retrieval-time (inference) forward only: call model.eval() first")
+        self._require_gpu()
+        return GraphedForward(self, (query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs),
+                              multimask_output, warmup)
+
+    @torch.no_grad()
     def forward_with_aux(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
                          multimask_output=True):
         """forward() plus {'masks': all 4 mask logits, 'iou': [B,4], 'best': [B]} for parity tests / analysis."""
@@ -93,3 +106,42 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
             return engine.forward(self.packed(T), self.image_encoder.cfg, self.support_branch.siglip.cfg,
                                   self.support_branch.mask_pooling_name, T, query_image_inputs, support_image_inputs,
                                   change_text_inputs, support_mask_inputs, multimask_output, return_aux=True)
+
+
+class GraphedForward:
+    """A captured forward (CirSegModelWithQuerySupportFeat.capture). __call__ takes the same four inputs (same shapes / dtypes
+    as at capture time; CPU tensors are copied over), replays the graph on the current stream and returns the three outputs.
+    The outputs are the graph's OWN buffers: they are overwritten by the next replay - pass clone=True to get copies."""
+
+    def __init__(self, model, inputs, multimask_output, warmup):
+        self.model, self.multimask_output = model, multimask_output
+        dev = model.device
+        self.T = model._resolve_dtype()
+        self.fingerprint = model._fingerprint()
+        with torch.cuda.device(dev):
+            self.static_in = [t.detach().to(dev).clone() for t in inputs]
+            W = model.packed(self.T)
+            args = (W, model.image_encoder.cfg, model.support_branch.siglip.cfg, model.support_branch.mask_pooling_name, self.T)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                  # warm-up off the capture: per-device kernel attributes, allocator pools
+                for _ in range(max(1, warmup)):
+                    engine.forward(*args, *self.static_in, multimask_output)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = engine.forward(*args, *self.static_in, multimask_output)
+
+    @torch.no_grad()
+    def __call__(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, clone=False):
+        if self.model._fingerprint() != self.fingerprint:
+            raise RuntimeError("cor_amd: the model's parameters changed (or moved) since capture(): capture again")
+        with torch.cuda.device(self.model.device):
+            for dst, src in zip(self.static_in, (query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs)):
+                if src.shape != dst.shape:
+                    raise ValueError(f"cor_amd: captured for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            self.graph.replay()
+        return tuple(t.clone() for t in self.static_out) if clone else self.static_out

@@ -1258,3 +1258,33 @@ def test_reverse_work_order_is_bit_identical():
         for variant in (0, 1):
             assert torch.equal(ops.sam_attention(qkv, pad, rh, rw, B, H, 64, win, variant=variant),
                                ops.sam_attention(qkv, pad, rh, rw, B, H, 64, win, variant=variant, reverse=True)), (win, variant)
+
+
+@pytest.mark.parametrize("mode", [F32, BF16])
+def test_graph_captured_forward_equals_eager(mode):
+    """model.capture(): the forward replayed as one hipGraph returns bit-identical outputs to the eager forward, for the
+    captured inputs and for NEW inputs copied into the captured buffers; stale captures (parameters changed) are refused."""
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    from cor_amd import utils
+    model = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskAdapterPooling")
+    utils.randomize_parameters(model, seed=3)
+    model = model.to(DEV).eval()
+    model.compute_dtype = mode
+    b0 = utils.synthetic_batch(2, torch.device(DEV), seed=0)
+    b1 = utils.synthetic_batch(2, torch.device(DEV), seed=1)
+    e0 = [t.clone() for t in model(**b0, multimask_output=True)]
+    e1 = [t.clone() for t in model(**b1, multimask_output=True)]
+    g = model.capture(**b0, multimask_output=True)
+    for want, batch in ((e0, b0), (e1, b1), (e0, b0)):
+        got = g(**batch, clone=True)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    host = {k: v.cpu() for k, v in b1.items()}                        # CPU tensors are copied over
+    for a, b in zip(g(**host), e1):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        g(**utils.synthetic_batch(3, torch.device(DEV), seed=0))
+    with torch.no_grad():
+        next(model.parameters()).add_(1.0)
+    with pytest.raises(RuntimeError):
+        g(**b0)
