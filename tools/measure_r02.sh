@@ -10,7 +10,7 @@ echo "bench done"; cut -c1-200 $O/bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_bench.json 2>/dev/null || exit 1
 echo "kernel trace done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_bench_$C -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_bench_$C -- python3 $R/bench.py --steps 1 --warmup 1 --graph 0 --no-cpu-baseline > /dev/null 2>&1 || exit 1
   timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_sim_$C -- python3 $R/tools/sim_bench.py 1m 4 > /dev/null 2>&1 || exit 1
 done
 echo "pmc done"
