@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=0, help="1: support branch on a second HIP stream (+4.5 % end to end; inflates per-kernel timings)")
+    ap.add_argument("--overlap", type=int, default=-1, help="1: support branch (SigLIP towers, adapter, fusion) beside the SAM encoder: a parallel branch of "
+                    "the captured graph / a second HIP stream in eager mode (+3-4 %% end to end). -1 (default): on under --graph 1, off in eager mode, "
+                    "where concurrent kernels would inflate the per-launch GEMM events")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): the timed steps replay the forward as ONE captured hipGraph "
                     "(model.capture: same kernels, lighter launch boundaries, +2.8 %% at batch 32, 1.4x at batch 1); ROCm cannot record "
                     "per-launch events inside a replayed graph, so the GEMM events behind `roofline` come from an eager re-run of the same "
@@ -126,7 +128,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
     from cor_amd import engine, ops, retrieval, utils
-    engine.OVERLAP_BRANCHES = bool(args.overlap)
+    overlap = bool(args.graph) if args.overlap < 0 else bool(args.overlap)
+    engine.OVERLAP_BRANCHES = overlap and not args.graph   # eager steps; the captured graph takes it as an argument
     from cor_amd.lib.build_model import build_model_with_query_support_feat
 
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -150,8 +153,8 @@ def main():
     graphed, launch_mode = None, "eager ctypes launches"
     if args.graph:
         try:
-            graphed = model.capture(**batch, multimask_output=True)
-            launch_mode = "hipGraph replay of the forward (model.capture); similarity search eager"
+            graphed = model.capture(**batch, multimask_output=True, overlap_branches=overlap)
+            launch_mode = "hipGraph replay of the forward (model.capture" + (", support branch as a parallel graph branch" if overlap else "") + "); similarity search eager"
         except Exception as e:                           # noqa: BLE001 - the bench must still produce its line
             launch_mode = f"eager ctypes launches (graph capture failed: {type(e).__name__}: {e})"
 
@@ -186,6 +189,7 @@ def main():
         # the same kernels, launched eagerly so that events can bracket every GEMM (not part of `value`)
         events_from = "an eager re-run of the same steps right after the timed region (no per-launch events inside a replayed hipGraph on ROCm)"
         ops.GEMM_PROFILE = prof
+        engine.OVERLAP_BRANCHES = False                  # one stream: a GEMM's events then bracket that GEMM alone
         for _ in range(args.steps):
             model(**batch, multimask_output=True)
         torch.cuda.synchronize()

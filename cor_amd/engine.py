@@ -417,7 +417,8 @@ def mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=False, p="m
     return final, iou, best, masks_all, keys
 
 
-OVERLAP_BRANCHES = False    # True: support branch on a second HIP stream (+4.5 % end to end: 61.9 -> 59.2 ms; off by default so per-kernel timings stay uncontended)
+OVERLAP_BRANCHES = False    # default of forward(overlap_branches=None); True: support branch on a second HIP stream (+3-4.5 % end to end; per-kernel
+                            # event timings are then contended, so the eager default stays off; a captured graph (model.capture) turns it on)
 _SIDE = {}
 
 
@@ -429,13 +430,15 @@ def _side_stream(device):
 
 
 def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
-            multimask_output=True, return_aux=False):
-    """ref: lib/sam_with_sup_branch.py:57-104."""
+            multimask_output=True, return_aux=False, overlap_branches=None):
+    """ref: lib/sam_with_sup_branch.py:57-104. overlap_branches (None = module default OVERLAP_BRANCHES): per-call choice."""
+    if overlap_branches is None:
+        overlap_branches = OVERLAP_BRANCHES
     B = query_image_inputs.shape[0]
     q_img = query_image_inputs.to(F32).contiguous()
     s_img = support_image_inputs.to(F32).contiguous()
     s_mask = support_mask_inputs.to(F32).contiguous()
-    if OVERLAP_BRANCHES:
+    if overlap_branches:
         # The support branch (SigLIP towers + ~100 tiny adapter/fusion kernels) is independent of the SAM encoder until
         # the mask decoder: enqueue it on a second HIP stream so its latency-bound kernels fill CUs the encoder leaves idle.
         main = torch.cuda.current_stream()

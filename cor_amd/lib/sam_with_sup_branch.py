@@ -85,16 +85,18 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
 
     @torch.no_grad()
     def capture(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, multimask_output=True,
-                warmup=2):
+                warmup=2, overlap_branches=True):
         """Capture forward() for THESE input shapes into a hipGraph and return a `GraphedForward`: calling it copies new
         inputs into the captured buffers and replays the ~600 kernel launches of a forward as ONE graph launch (the eager
         path pays one ctypes call + one launch per kernel: launch-bound at small batch). The example inputs are only read
-        during warm-up and capture; the packed weights are captured by address (re-capture after changing parameters)."""
+        during warm-up and capture; the packed weights are captured by address (re-capture after changing parameters).
+        overlap_branches: the support branch (SigLIP towers, adapter, fusion: ~200 small kernels that do not fill the chip) is
+        captured on a second stream, i.e. as a parallel branch of the graph beside the SAM encoder (+3-4 % at batch 32)."""
         if self.training:
             raise RuntimeError("cor_amd implements the retrieval-time (inference) forward only: call model.eval() first")
         self._require_gpu()
         return GraphedForward(self, (query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs),
-                              multimask_output, warmup)
+                              multimask_output, warmup, overlap_branches)
 
     @torch.no_grad()
     def forward_with_aux(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
@@ -113,7 +115,7 @@ class GraphedForward:
     as at capture time; CPU tensors are copied over), replays the graph on the current stream and returns the three outputs.
     The outputs are the graph's OWN buffers: they are overwritten by the next replay - pass clone=True to get copies."""
 
-    def __init__(self, model, inputs, multimask_output, warmup):
+    def __init__(self, model, inputs, multimask_output, warmup, overlap_branches=True):
         self.model, self.multimask_output = model, multimask_output
         dev = model.device
         self.T = model._resolve_dtype()
@@ -126,12 +128,12 @@ class GraphedForward:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                  # warm-up off the capture: per-device kernel attributes, allocator pools
                 for _ in range(max(1, warmup)):
-                    engine.forward(*args, *self.static_in, multimask_output)
+                    engine.forward(*args, *self.static_in, multimask_output, overlap_branches=overlap_branches)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.static_out = engine.forward(*args, *self.static_in, multimask_output)
+                self.static_out = engine.forward(*args, *self.static_in, multimask_output, overlap_branches=overlap_branches)
 
     @torch.no_grad()
     def __call__(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, clone=False):

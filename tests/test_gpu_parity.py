@@ -1274,7 +1274,11 @@ def test_graph_captured_forward_equals_eager(mode):
     b1 = utils.synthetic_batch(2, torch.device(DEV), seed=1)
     e0 = [t.clone() for t in model(**b0, multimask_output=True)]
     e1 = [t.clone() for t in model(**b1, multimask_output=True)]
-    g = model.capture(**b0, multimask_output=True)
+    g_serial = model.capture(**b0, multimask_output=True, overlap_branches=False)
+    for a, b in zip(g_serial(**b1, clone=True), e1):
+        assert torch.equal(a, b)
+    del g_serial
+    g = model.capture(**b0, multimask_output=True)                   # support branch as a parallel branch of the graph (default)
     for want, batch in ((e0, b0), (e1, b1), (e0, b0)):
         got = g(**batch, clone=True)
         for a, b in zip(got, want):

@@ -25,6 +25,6 @@ echo "micro benches done"
 timeout -k 10 300 python3 bench.py --sam sam_large --siglip ViT-L-16-SigLIP-384 --batch 64 --no-cpu-baseline > $O/bench_L.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 bench.py --dtype f32 --batch 8 --no-cpu-baseline > $O/bench_f32.json 2>/dev/null || exit 1
 timeout -k 10 300 python3 bench.py --host-inputs 1 --no-cpu-baseline > $O/bench_host.json 2>/dev/null || exit 1
-timeout -k 10 300 python3 bench.py --overlap 1 --no-cpu-baseline > $O/bench_overlap.json 2>/dev/null || exit 1
+timeout -k 10 300 python3 bench.py --graph 0 --no-cpu-baseline > $O/bench_eager.json 2>/dev/null || exit 1
 echo "other configs done"
 timeout -k 10 400 python3 tools/race_screen.py 20 > $O/race_screen.txt 2>&1; echo "race rc=$?"; tail -2 $O/race_screen.txt
