@@ -483,8 +483,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 // fma + max + sub + exp2 + cvt_pk/2  (-64 VALU, +10 MFMAs per tile). (Round 2 first tried the same fold through the
 // accumulator's start values - one add per score instead of two ops - which measured SLOWER: the adds sat on the MFMA's
 // critical path; an MFMA that starts from the inline constant 0 does not wait for VALU results.)
-template <typename TO, int FOLD>     // 0: fma form; 1: row bias - reference folded; 2: column bias folded too
-__global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
+template <typename TO, int FOLD, int NW = 4>     // FOLD 0: fma form; 1: row bias - reference folded; 2: column bias folded too
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(const FlashArgs a) {   // NW waves x 32 queries per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   const int g2 = a.grid * a.grid;
   const bf16_t* kvbase = a.q + (long)b * g2 * a.d3 + head * 64;
 
-  int tq = qt_ * 128 + wave * 32 + r;
+  int tq = qt_ * (NW * 32) + wave * 32 + r;
   const bool qvalid = tq < a.Tq;
   tq = min(tq, a.Tq - 1);
   const int qh = tq / S, qw = tq - qh * S;
@@ -511,7 +511,9 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUX_PER_WAVE);
   float wreg[2][16];
   {
-    float* scr = (float*)(smem + wave * AUX_PER_WAVE);            // aliases the K/V rings: barrier before staging
+    // scratch of the table products: aliases the K/V rings (48 KiB: six waves; barrier before staging), waves 6-7 of the
+    // 8-wave form use 16 KiB behind the row-bias tables
+    float* scr = (float*)(smem + (NW == 8 && wave >= 6 ? K_BYTES + V_BYTES + NW * AUX_PER_WAVE + (wave - 6) * AUX_PER_WAVE : wave * AUX_PER_WAVE));
 #pragma unroll 1
     for (int tbl = 0; tbl < 2; ++tbl) {
       const float* table = tbl == 0 ? a.rel_h : a.rel_w;
@@ -610,19 +612,23 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   const int srow = tid >> 3, sch = tid & 7;
   const int kswz = (sch ^ ((srow >> 1) & 7)) * 8;          // source chunk (elements) of the K copy; (32 + srow)>>1 & 7 is the same
   const bf16_t* kv0 = kvbase + (long)srow * a.d3;           // row srow of tile 0; + 32*d3 for the second chunk
+  // (NW = 8: 512 threads, one chunk each - half the LDS-DMA instructions per wave and tile, and K/V cross L2 -> LDS once per
+  // 256 queries instead of once per 128)
   auto issue_k = [&](int t, int slot) {
     const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + a.H * 64 + kswz;
     const unsigned d = lds0 + slot * TILE_B + wofs;
-    glds16(p0, d); glds16(p0 + 32L * a.d3, d + 4096);
+    glds16(p0, d);
+    if (NW == 4) glds16(p0 + 32L * a.d3, d + 4096);
   };
   auto issue_v = [&](int t, int slot) {
     const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + sch * 8;
     const unsigned d = lds0 + K_BYTES + slot * TILE_B + wofs;
-    glds16(p0, d); glds16(p0 + 32L * a.d3, d + 4096);
+    glds16(p0, d);
+    if (NW == 4) glds16(p0 + 32L * a.d3, d + 4096);
   };
   issue_k(0, 0); issue_k(1, 1); issue_k(2, 2); issue_v(0, 0);
   *(uint4*)(Vring + 2 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 2)
-  *(uint4*)(Vring + 2 * TILE_B + 4096 + tid * 16) = make_uint4(0, 0, 0, 0);
+  if (NW == 4) *(uint4*)(Vring + 2 * TILE_B + 4096 + tid * 16) = make_uint4(0, 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -814,7 +820,8 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     c3 = c3p1;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 stay in flight
+    if (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 (NW = 8: 2) stay in flight
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __syncthreads();
   };
   f32x16 s2[2];
@@ -855,7 +862,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 
   const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
   auto off = [&](int j) -> long {
-    const int tj = qt_ * 128 + wave * 32 + j;
+    const int tj = qt_ * (NW * 32) + wave * 32 + j;
     return tj < a.Tq ? ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64 : -1L;
   };
   store_o_rows<TO, 64>(o, inv, (char*)aux, (TO*)a.o, lane, off);   // the wave's row-bias table is dead: 8 KiB of private staging
@@ -1097,14 +1104,14 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO, int FOLD>
+template <typename TO, int FOLD, int NW = 4>
 int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
-  const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
+  const size_t lds = 6 * TILE_B + NW * AUX_PER_WAVE + (NW == 8 ? 2 * AUX_PER_WAVE : 0);    // 80 KiB: two blocks per CU; NW = 8: 128 KiB, one
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD, NW>, (int)lds, once);
   FlashArgs b = a;
-  b.nqt = cdiv(a.Tq, 128);
-  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  b.nqt = cdiv(a.Tq, NW * 32);
+  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD, NW>), dim3(b.nqt * a.H * nb), dim3(NW * 64), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
 }
@@ -1112,7 +1119,8 @@ int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
 // (a.scale_log2 == 1); raw-q callers get the fma form.
 template <typename TO>
 int launch_global_pipe(const FlashArgs& a, int nb, int fold, hipStream_t s) {
-  if (a.scale_log2 != 1.0f) fold = 0;
+  if (a.scale_log2 != 1.0f && fold != 8) fold = 0;
+  if (fold == 8) return launch_global_pipe_<TO, 0, 8>(a, nb, s);     // 8-wave blocks (variant 4)
   return fold == 2 ? launch_global_pipe_<TO, 2>(a, nb, s) : fold == 1 ? launch_global_pipe_<TO, 1>(a, nb, s) : launch_global_pipe_<TO, 0>(a, nb, s);
 }
 
@@ -1143,7 +1151,9 @@ int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
 // column + row bias and the running reference (2) or the row bias and reference only (3) as extra k-steps of the score MFMA
 // (needs q_prescale = scale * log2 e). Measured at B = 32 (profiles/r02_attention_fold_ablation.jsonl): variant 0 2.29-2.39 ms,
 // variant 3 2.41-2.42 ms (-33 VALU, +2 MFMAs per tile: +1 %), variant 2 2.57-2.68 ms (-64 VALU, +10 MFMAs: +12 %), variant 1
-// 2.40-2.51 ms: the kernel's time does not follow its VALU count, so the default stays the fma form.
+// 2.40-2.51 ms: the kernel's time does not follow its VALU count, so the default stays the fma form. 4 = the default arithmetic in
+// 8-wave blocks (256 queries per block: K/V cross L2 -> LDS once per 256 queries, half the LDS-DMA instructions per wave):
+// bit-identical, 2.44-2.46 vs 2.31-2.32 ms (the per-tile barrier then spans 8 waves).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -1175,8 +1185,8 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
-    if (variant == 0 || variant == 2 || variant == 3) {
-      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : 0;
+    if (variant == 0 || variant == 2 || variant == 3 || variant == 4) {
+      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : 0;
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, fold, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, fold, s);
     }

@@ -90,7 +90,8 @@ int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, cons
  * pipelined over key tiles; windowed: win_attn, one 7-wave block per (window, head)); 1 = the round-1 chain forms of the same
  * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py); 2 / 3 = global
  * attention with the biases and the running reference (2) or the row bias and reference only (3) as extra k-steps of the score
- * MFMA (need q_prescale = scale * log2 e; A/B partners, measured 12 % / 1 % slower than 0). */
+ * MFMA (need q_prescale = scale * log2 e; A/B partners, measured 12 % / 1 % slower than 0); 4 = global attention in 8-wave
+ * blocks (bit-identical to 0, 5 % slower). */
 
 /* Which kernel family cor_attention (sam_window = -1) / cor_sam_attention (0 = global, > 0 = windowed) runs for 16-byte-aligned
  * operands of this shape: bf16 with head_dim 64 / 72 / 80 is on the matrix cores. Pure function (no launch). */
