@@ -120,12 +120,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
     from cor_amd import engine, ops, retrieval, utils
     overlap = bool(args.graph) if args.overlap < 0 else bool(args.overlap)
@@ -150,13 +144,20 @@ def main():
     if h2d is not None:
         h2d.stage(host_batch)
 
-    graphed, launch_mode = None, "eager ctypes launches"
+    graphed, launch_mode = None, "eager ctypes launches"     # (captured BEFORE the process group exists: no RCCL host threads beside the capture)
     if args.graph:
         try:
             graphed = model.capture(**batch, multimask_output=True, overlap_branches=overlap)
             launch_mode = "hipGraph replay of the forward (model.capture" + (", support branch as a parallel graph branch" if overlap else "") + "); similarity search eager"
         except Exception as e:                           # noqa: BLE001 - the bench must still produce its line
             launch_mode = f"eager ctypes launches (graph capture failed: {type(e).__name__}: {e})"
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
     def step():
         if h2d is not None:

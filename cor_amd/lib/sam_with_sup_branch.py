@@ -132,7 +132,8 @@ class GraphedForward:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: API calls of OTHER host threads (e.g. a process group's watchdog) must not invalidate the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.static_out = engine.forward(*args, *self.static_in, multimask_output, overlap_branches=overlap_branches)
 
     @torch.no_grad()
