@@ -173,3 +173,24 @@ def test_preprocess_oracle_vs_live_pillow_full_size():
         assert np.array_equal(got, want)
     x = OP.preprocess_image(a[:, :, 0], 384, normalize=False)
     assert x.shape == (1, 384, 384) and x.dtype == np.float32 and 0.0 <= x.min() and x.max() <= 1.0
+
+
+def test_mask_resize_restatement_vs_pillow_and_torch():
+    """The oracle's restatement of cv2.resize(INTER_LINEAR) on float probability maps (utils/vailder.py:459-473; cv2 is not installed
+    here, so this half of the post-processing is NOT pinned by the reference itself) against two independent implementations of
+    the same published arithmetic (half-pixel centres, two taps, edge replication, no antialiasing): torch's
+    F.interpolate(bilinear, align_corners=False) for up- and down-scaling, and Pillow's float ("F" mode) BILINEAR resize for
+    up-scaling (Pillow antialiases when shrinking, cv2 does not)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from oracle.support import bilinear_resize
+    g = torch.Generator().manual_seed(11)
+    for (ih, iw, oh, ow) in ((256, 256, 480, 640), (256, 256, 333, 500), (256, 256, 1024, 1024), (256, 256, 257, 300), (256, 256, 200, 120), (64, 64, 37, 91)):
+        x = torch.rand((1, 1, ih, iw), generator=g)
+        got = bilinear_resize(x, oh, ow)
+        ref_t = torch.nn.functional.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False)
+        assert float((got - ref_t).abs().max()) <= 1e-5, (ih, iw, oh, ow)        # tap weights in float32 here and there: rounding only
+        if oh >= ih and ow >= iw:
+            pil = np.asarray(Image.fromarray(x[0, 0].numpy(), mode="F").resize((ow, oh), Image.BILINEAR))
+            assert float(np.abs(got[0, 0].numpy() - pil).max()) <= 3e-5, (ih, iw, oh, ow)   # Pillow computes its weights in double
