@@ -483,8 +483,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 // fma + max + sub + exp2 + cvt_pk/2  (-64 VALU, +10 MFMAs per tile). (Round 2 first tried the same fold through the
 // accumulator's start values - one add per score instead of two ops - which measured SLOWER: the adds sat on the MFMA's
 // critical path; an MFMA that starts from the inline constant 0 does not wait for VALU results.)
-template <typename TO, int FOLD, int NW = 4>     // FOLD 0: fma form; 1: row bias - reference folded; 2: column bias folded too
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(const FlashArgs a) {   // NW waves x 32 queries per block
+template <typename TO, int FOLD, int NW = 4, bool STAMP = false>     // FOLD 0: fma form; 1: row bias - reference folded; 2: column bias folded too
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(const FlashArgs a) {   // STAMP: timing probe (tools/attn_stamps.py): cycle sums instead of outputs   // NW waves x 32 queries per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -679,12 +679,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
   __syncthreads();                                      // every wave is done with K tile 0 before iteration 0 refills its slot
 
   int c3 = 0;                                           // t % 3
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};      // STAMP: cycles in [DMA issue | phase A | reference update | phase B | vmcnt wait | barrier]
   // one key tile; S(t) arrives in `s`, S(t+1) leaves in `sn`. FOLD consumes the raw MFMA result in the NEXT iteration, so the
   // loop below runs two tiles per trip with the two register sets swapping roles (a single-tile loop copied 32 registers per tile)
   auto tile_step = [&](const int t, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
     const int c3p1 = c3 == 2 ? 0 : c3 + 1, c3p2 = c3 == 0 ? 2 : c3 - 1;      // (t+1) % 3, (t+2) % 3 = (t-1) % 3
+    unsigned long long ts[8];
+    auto stamp = [&](int i) { if (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } };
+    stamp(0);
+    // (the slots are free from the top of the iteration: K(t) and V(t-2) were last read in iteration t-1; issuing the four copies
+    // after phase A, after phase B or split between them instead measured +-0.5 %)
     issue_k(t + 3, c3);                                 // over K(t), last read in iteration t-1
     issue_v(t + 1, c3p1);                               // over V(t-2), last read in iteration t-1
+    stamp(1);
     const char* Vs = Vring + c3p2 * TILE_B;             // V(t-1)
     const char* Ks = Kring + c3p1 * TILE_B;             // K(t+1)
     const float rh = FOLD ? aux[min(t + 1, nt - 1) * 32 + r] : aux[t * 32 + r];   // FOLD: row bias of the NEXT tile (folded into S(t+1))
@@ -754,6 +761,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(2);
     float msub = 0.f;
     if (FOLD) {
       // reference update only when a tile maximum exceeds it by 2^8 (lazy rescale); S(t+1) is issued below, after the update,
@@ -787,6 +795,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
       }
       msub = m - rh;                                    // p = 2^(x + rh - m)
     }
+    stamp(3);
     // ---- phase B: QK(t+1) MFMAs beside exp2 and packing of P(t)
     uint4 kf[8];
 #pragma unroll
@@ -820,9 +829,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     }
     __builtin_amdgcn_sched_barrier(0);
     c3 = c3p1;
+    stamp(4);
     if (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 (NW = 8: 2) stay in flight
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    stamp(5);
     __syncthreads();
+    stamp(6);
+    if (STAMP) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tsum[i] += ts[i + 1] - ts[i];
+    }
   };
   f32x16 s2[2];
   if (FOLD == 2) {
@@ -860,6 +876,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
       }
   }
 
+  if (STAMP) {                                          // probe build: no outputs, six cycle sums per wave at the start of `o`
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ((unsigned long long*)a.o)[((long)blockIdx.x * NW + wave) * 8 + i] = tsum[i];
+      ((unsigned long long*)a.o)[((long)blockIdx.x * NW + wave) * 8 + 6] = (unsigned long long)(o[0][0] + lsum[0] != 12345.f);   // keep the arithmetic alive
+    }
+    return;
+  }
   const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
   auto off = [&](int j) -> long {
     const int tj = qt_ * (NW * 32) + wave * 32 + j;
@@ -1104,14 +1128,14 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO, int FOLD, int NW = 4>
+template <typename TO, int FOLD, int NW = 4, bool STAMP = false>
 int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + NW * AUX_PER_WAVE + (NW == 8 ? 2 * AUX_PER_WAVE : 0);    // 80 KiB: two blocks per CU; NW = 8: 128 KiB, one
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD, NW>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD, NW, STAMP>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, NW * 32);
-  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD, NW>), dim3(b.nqt * a.H * nb), dim3(NW * 64), lds, s, b);
+  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD, NW, STAMP>), dim3(b.nqt * a.H * nb), dim3(NW * 64), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
 }
@@ -1119,8 +1143,9 @@ int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
 // (a.scale_log2 == 1); raw-q callers get the fma form.
 template <typename TO>
 int launch_global_pipe(const FlashArgs& a, int nb, int fold, hipStream_t s) {
-  if (a.scale_log2 != 1.0f && fold != 8) fold = 0;
+  if (a.scale_log2 != 1.0f && fold < 8) fold = 0;
   if (fold == 8) return launch_global_pipe_<TO, 0, 8>(a, nb, s);     // 8-wave blocks (variant 4)
+  if (fold == 9) return launch_global_pipe_<TO, 0, 4, true>(a, nb, s);   // timing probe (variant 9): cycle sums instead of outputs
   return fold == 2 ? launch_global_pipe_<TO, 2>(a, nb, s) : fold == 1 ? launch_global_pipe_<TO, 1>(a, nb, s) : launch_global_pipe_<TO, 0>(a, nb, s);
 }
 
@@ -1153,7 +1178,8 @@ int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
 // variant 3 2.41-2.42 ms (-33 VALU, +2 MFMAs per tile: +1 %), variant 2 2.57-2.68 ms (-64 VALU, +10 MFMAs: +12 %), variant 1
 // 2.40-2.51 ms: the kernel's time does not follow its VALU count, so the default stays the fma form. 4 = the default arithmetic in
 // 8-wave blocks (256 queries per block: K/V cross L2 -> LDS once per 256 queries, half the LDS-DMA instructions per wave):
-// bit-identical, 2.44-2.46 vs 2.31-2.32 ms (the per-tile barrier then spans 8 waves).
+// bit-identical, 2.44-2.46 vs 2.31-2.32 ms (the per-tile barrier then spans 8 waves). 9 = timing probe of the default kernel:
+// per-wave s_memtime sums per loop section are written INSTEAD of the outputs (tools/attn_stamps.py).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -1185,8 +1211,8 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
-    if (variant == 0 || variant == 2 || variant == 3 || variant == 4) {
-      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : 0;
+    if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 9) {
+      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : variant == 9 ? 9 : 0;
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, fold, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, fold, s);
     }
