@@ -148,6 +148,8 @@ def main():
     if args.graph:
         try:
             graphed = model.capture(**batch, multimask_output=True, overlap_branches=overlap)
+            if not args.host_inputs:                     # resident inputs: the batch IS the graph's input buffers (no per-step D2D copy)
+                batch = dict(zip(("query_image_inputs", "support_image_inputs", "change_text_inputs", "support_mask_inputs"), graphed.static_in))
             launch_mode = "hipGraph replay of the forward (model.capture" + (", support branch as a parallel graph branch" if overlap else "") + "); similarity search eager"
         except Exception as e:                           # noqa: BLE001 - the bench must still produce its line
             launch_mode = f"eager ctypes launches (graph capture failed: {type(e).__name__}: {e})"
