@@ -893,6 +893,250 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Global SAM attention, PING-PONG form (variant 5): the arithmetic of flash_global_pipe in 8-wave blocks (256 queries) whose two
+// wave groups (waves 0-3 / 4-7: waves w and w + 4 share a SIMD) run ONE barrier interval apart, so that on every SIMD one
+// wave is in its matrix segment while its partner is in its softmax segment (the stamps of the default kernel show the matrix
+// and vector work of two co-resident, unsynchronised waves barely overlapping). A wave's iteration t is
+//     M(t):  O^T += V(t-1)^T . P(t-1)^T (+ row sums)  and  S(t)^T = K(t) . Q^T          (20 MFMAs, fragments read at the top)
+//     V(t):  scale + bias + max of S(t), lazy reference update, exp2 and bf16 packing of P(t)            (VALU only)
+// with a block barrier after each segment; group 1 executes one extra barrier before its loop, group 0 one after. (No score
+// tile is computed ahead: inside one wave M and V alternate strictly, the overlap comes from the partner - 32 registers less.)
+// K / V rings of FOUR tiles: every wave copies its 8 rows of K(t+3) and V(t+2) at the top of M(t) (both slots were last read
+// in M(t-1), which the lagging group finished before the barrier group 0 has just passed) and waits with vmcnt(2) at the
+// end of V(t), i.e. for the copies of iteration t-1; those are published by the barrier the lagging group passes at the end
+// of its V(t) and first read in M(t+2). LDS = 64 KiB rings + 64 KiB row-bias tables: one block per CU, two waves per SIMD.
+template <typename TO, bool STAMP = false, int ABL = 0>   // ABL: timing ablations of the probe build only (1 no exp2, 2 no max chain, 3 no fma, 4 no frag reads)
+__global__ void __launch_bounds__(512, 1) flash_global_pp(const FlashArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 8, K_BYTES = 4 * TILE_B, V_BYTES = 4 * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi0_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int wi_ = a.rev ? (int)gridDim.x - 1 - wi0_ : wi0_;
+  const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
+  const int head = hb_ % a.H, b = hb_ / a.H;
+  const int S = a.S;                                   // 64
+  const int g2 = a.grid * a.grid;
+  const bf16_t* kvbase = a.q + (long)b * g2 * a.d3 + head * 64;
+
+  int tq = qt_ * (NW * 32) + wave * 32 + r;
+  tq = min(tq, a.Tq - 1);
+  const int qh = tq / S, qw = tq - qh * S;
+  const long orow = (long)b * g2 + tq;
+  const bf16_t* qp = a.q + orow * a.d3 + head * 64;
+  uint4 qf[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qf[c] = *(const uint4*)(qp + 16 * c + 8 * h);
+
+  // ---- relative-position tables (log2 domain): row part -> aux[kh][q] (LDS), column part -> 32 registers
+  float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUX_PER_WAVE);
+  float wreg[2][16];
+  {
+    float* scr = (float*)(smem + wave * AUX_PER_WAVE);            // aliases the K/V rings (64 KiB): barrier before staging
+#pragma unroll 1
+    for (int tbl = 0; tbl < 2; ++tbl) {
+      const float* table = tbl == 0 ? a.rel_h : a.rel_w;
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
+          const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
+                                                              __builtin_bit_cast(bf16x8, qf[c]), acc[jb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
+        if (tbl == 0) {
+#pragma unroll 4
+          for (int i = 0; i < 32; ++i) {
+            const int kh = 32 * h + i, j = qh + (S - 1) - kh;
+            if ((j >> 6) == half) aux[kh * 32 + r] = scr[(j & 63) * 32 + r];
+          }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int kw = kb * 32 + acc_row(e, h), j = qw + (S - 1) - kw;
+              if ((j >> 6) == half) wreg[kb][e] = scr[(j & 63) * 32 + r];
+            }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- staging: LDS-DMA, one 16-B chunk per thread and tile (512 chunks = 64 rows x 128 B); K swizzled on the source side
+  char* Kring = smem; char* Vring = smem + K_BYTES;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  const unsigned wofs = wave * 1024u;
+  const int nt = a.Tk / KT;
+  const int srow = tid >> 3, sch = tid & 7;
+  const int kswz = (sch ^ ((srow >> 1) & 7)) * 8;
+  const bf16_t* kv0 = kvbase + (long)srow * a.d3;
+  auto issue_k = [&](int t) {
+    glds16(kv0 + (long)min(t, nt - 1) * KT * a.d3 + a.H * 64 + kswz, lds0 + (t & 3) * TILE_B + wofs);
+  };
+  auto issue_v = [&](int t) {
+    glds16(kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + sch * 8, lds0 + K_BYTES + (t & 3) * TILE_B + wofs);
+  };
+  issue_k(0); issue_k(1); issue_k(2); issue_v(0); issue_v(1);
+  *(uint4*)(Vring + 3 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- fragment read maps
+  const int sw = (lane >> 1) & 7;
+  int kch[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kch[c] = r * 128 + (((2 * c + h) ^ sw) << 4);
+  const int v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  f32x16 o[2], s[2], lsum;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lsum[e] = 0.f;
+  float m = -INFINITY;
+  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
+  uint4 pf[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) { pf[kb][0] = make_uint4(0, 0, 0, 0); pf[kb][1] = make_uint4(0, 0, 0, 0); }
+
+  // fragments of the NEXT matrix segment are read at the top of the softmax segment before it (their LDS latency hides under
+  // the VALU work): vf = V(t-1), kf = K(t) for M(t)
+  uint4 vf[8], kf[8];
+  auto read_frags = [&](int tv, int tk) {              // V(tv) and K(tk) (slot = tile & 3)
+    const char* Vs = Vring + (tv & 3) * TILE_B;
+    const char* Ks = Kring + (tk & 3) * TILE_B;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
+      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + db * 64 + v_tr;
+      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
+      const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+      vf[i] = make_uint4(u0.x, u0.y, u1.x, u1.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
+  };
+  read_frags(3, 0);                                     // V(-1) (the zero tile in slot 3), K(0)
+  if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one interval behind group 0
+
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};      // STAMP: [copy issue | M | barrier | V | vmcnt wait | barrier]
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    unsigned long long ts[8];
+    auto stamp = [&](int i) { if (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } };
+    // ================= M(t): copies of K(t+3), V(t+2); QK(t); PV(t-1) + row sums
+    stamp(0);
+    issue_k(t + 3);
+    issue_v(t + 2);
+    const float rh = aux[t * 32 + r];                   // (wave-private table: read here, ahead of the 24 fragment reads of V(t))
+    stamp(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
+      if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(2);
+    __builtin_amdgcn_s_barrier();
+    stamp(3);
+    // ================= V(t): fragments for M(t+1) = V(t), K(t+1) (published by the barrier just passed); softmax of S(t) -> P(t)
+    if (ABL != 4) read_frags(t, t + 1);
+    float mloc = -INFINITY, ml1 = -INFINITY, ml2 = -INFINITY, ml3 = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float x0 = ABL == 3 ? s[kb][e] : fmaf(s[kb][e], a.scale_log2, wreg[kb][e]), x1 = ABL == 3 ? s[kb][e + 1] : fmaf(s[kb][e + 1], a.scale_log2, wreg[kb][e + 1]);
+        s[kb][e] = x0; s[kb][e + 1] = x1;
+        if (ABL != 2) {                                 // four independent maximum chains
+          float& mm = ((e >> 1) & 3) == 0 ? mloc : ((e >> 1) & 3) == 1 ? ml1 : ((e >> 1) & 3) == 2 ? ml2 : ml3;
+          mm = fmaxf(mm, fmaxf(x0, x1));
+        }
+      }
+    if (ABL == 2) mloc = s[0][0];
+    else mloc = fmaxf(fmaxf(mloc, ml1), fmaxf(ml2, ml3));
+    mloc = fmaxf(mloc, other_half(mloc)) + rh;          // true tile max (x + rh)
+    if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {     // lazy rescale
+      const float mnew = fmaxf(m, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      m = mnew;
+      lsum[0] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+    }
+    const float msub = m - rh;                          // p = 2^(x + rh - m)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 p;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) p[e] = ABL == 1 ? s[kb][e] - msub : __builtin_amdgcn_exp2f(s[kb][e] - msub);
+      pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+      pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
+    }
+    stamp(4);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // the copies of iteration t-1 (K(t+2), V(t+1)) have landed; this iteration's 2 stay in flight
+    stamp(5);
+    __builtin_amdgcn_s_barrier();
+    stamp(6);
+    if (STAMP) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tsum[i] += ts[i + 1] - ts[i];
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
+  // PV(nt-1) and its row sums: vf already holds V(nt-1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail copies must not outlive the block
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
+    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
+    if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
+  }
+  if (STAMP) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ((unsigned long long*)a.o)[((long)blockIdx.x * NW + wave) * 8 + i] = tsum[i];
+      ((unsigned long long*)a.o)[((long)blockIdx.x * NW + wave) * 8 + 6] = (unsigned long long)(o[0][0] + lsum[0] != 12345.f);
+    }
+    return;
+  }
+  const float inv = 1.0f / lsum[0];
+  auto off = [&](int j) -> long {
+    const int tj = qt_ * (NW * 32) + wave * 32 + j;
+    return tj < a.Tq ? ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64 : -1L;
+  };
+  store_o_rows<TO, 64>(o, inv, (char*)aux, (TO*)a.o, lane, off);   // the wave's row-bias table is dead: 8 KiB of private staging
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Windowed SAM attention (14x14 windows), ONE block per (window, head): 7 waves x 32 queries (224 slots for the 196 queries,
 // 12.5 % padding; flash_fwd<2> ran two 128-query blocks per (window, head): 23 % padding and every K/V byte staged twice).
 //   * K and V of the whole window (2 x 224 rows x 128 B = 56 KiB) are staged ONCE by LDS-DMA while the waves build their
@@ -1141,9 +1385,26 @@ int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
 }
 // FOLD (bias and reference as extra k-steps of the score MFMA, see the kernel header) needs q pre-scaled by scale * log2 e
 // (a.scale_log2 == 1); raw-q callers get the fma form.
+template <typename TO, bool STAMP = false, int ABL = 0>
+int launch_global_pp(const FlashArgs& a, int nb, hipStream_t s) {
+  const size_t lds = 8 * TILE_B + 8 * AUX_PER_WAVE;    // 128 KiB: one 8-wave block per CU
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)flash_global_pp<TO, STAMP, ABL>, (int)lds, once);
+  FlashArgs b = a;
+  b.nqt = cdiv(a.Tq, 256);
+  hipLaunchKernelGGL((flash_global_pp<TO, STAMP, ABL>), dim3(b.nqt * a.H * nb), dim3(512), lds, s, b);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
 template <typename TO>
 int launch_global_pipe(const FlashArgs& a, int nb, int fold, hipStream_t s) {
-  if (a.scale_log2 != 1.0f && fold < 8) fold = 0;
+  if (fold == 5) return launch_global_pp<TO>(a, nb, s);
+  if (fold == 10) return launch_global_pp<TO, true>(a, nb, s);    // timing probe of the ping-pong form (variant 10)
+  if (fold >= 11 && fold <= 14) {                                    // probe-only ablations of the softmax segment (tools/attn_stamps.py B pp N)
+    return fold == 11 ? launch_global_pp<TO, true, 1>(a, nb, s) : fold == 12 ? launch_global_pp<TO, true, 2>(a, nb, s)
+         : fold == 13 ? launch_global_pp<TO, true, 3>(a, nb, s) : launch_global_pp<TO, true, 4>(a, nb, s);
+  }
+  if (a.scale_log2 != 1.0f && fold < 5) fold = 0;
   if (fold == 8) return launch_global_pipe_<TO, 0, 8>(a, nb, s);     // 8-wave blocks (variant 4)
   if (fold == 9) return launch_global_pipe_<TO, 0, 4, true>(a, nb, s);   // timing probe (variant 9): cycle sums instead of outputs
   return fold == 2 ? launch_global_pipe_<TO, 2>(a, nb, s) : fold == 1 ? launch_global_pipe_<TO, 1>(a, nb, s) : launch_global_pipe_<TO, 0>(a, nb, s);
@@ -1211,8 +1472,8 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
-    if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 9) {
-      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : variant == 9 ? 9 : 0;
+    if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 9 || (variant >= 10 && variant <= 14)) {
+      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : variant == 5 ? 5 : variant >= 9 ? variant : 0;
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, fold, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, fold, s);
     }

@@ -369,6 +369,9 @@ def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
     report(f"global_attn_pipe_B{B}_H{H}_amp{amp}", out, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
     out8 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=4)     # 8-wave blocks: same arithmetic per wave
     assert torch.equal(out8, out)
+    out_pp = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=5)   # ping-pong form: same arithmetic per wave
+    assert torch.equal(out_pp, out)
+    assert torch.equal(out_pp, ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=5))
     # q_prescale path (what the engine runs): scale * log2 e folded into the q third by the caller; bias and running
     # reference folded into the score accumulator. One more bf16 rounding on the q side than the chain form (which scales in
     # fp32): at amp = 6 (|score| ~ 100 log2 units, nearly one-hot softmax) that moves near-ties, hence the wider budget there.
