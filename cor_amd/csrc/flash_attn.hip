@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       const float mnew = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m - mnew);
       m = mnew;
-      lsum[0] *= alpha;
+      lsum[1] *= alpha; lsum[2] *= alpha;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -409,11 +409,14 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
       f32x16 p;
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub);
+      // row sums on the VALU (this lane's 16 keys of the block; the lane halves are added once at the end): beside MFMAs a
+      // vector instruction costs ~2 cycles, a ones-row MFMA 32 (profiles/r02_valu_mfma_issue_probe.jsonl)
+      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
+      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
-    // O^T += V^T . P^T, one 16-key K-step at a time (its DB transposed V fragments first); row sums of P on the matrix pipe:
-    // ones . P^T leaves sum_k P[k][q] (over the bf16-rounded P, as the numerator) in every row of lsum
+    // O^T += V^T . P^T, one 16-key K-step at a time (its DB transposed V fragments first)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int kb = kk >> 1, ks = kk & 1;
@@ -429,7 +432,6 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #pragma unroll
       for (int db = 0; db < DB; ++db)
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[db]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-      lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     if (more) FA_LSTORE((t + 1) & 1)
     __syncthreads();
@@ -442,7 +444,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #undef FA_GLOAD
 #undef FA_LSTORE
 
-  const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
+  const float lhalf = lsum[1] + lsum[2];
+  const float inv = 1.0f / (lhalf + other_half(lhalf)); // full row sum: both lane halves
   // staging: the K/V buffers (every wave is past the last tile's barrier), 8 KiB per wave
   auto off = [&](int j) -> long {
     const int tj = qt_ * 128 + wave * 32 + j;
@@ -460,12 +463,14 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 // Global SAM attention, SOFTWARE-PIPELINED over key tiles (variant 1, default). flash_fwd<1> runs each wave's tile as a chain
 // QK^T MFMAs -> softmax VALU -> PV MFMAs, so the matrix pipe idles during the softmax and the VALU during the MFMAs.
 // Here iteration t interleaves, in ONE instruction stream (an MFMA holds the VALU issue for 8 of its 32 cycles),
-//     phase A:  O^T += V(t-1)^T . P(t-1)^T  (8 MFMAs + 4 row-sum MFMAs)   with   scale + column bias + max of S(t)  (VALU)
+//     phase A:  O^T += V(t-1)^T . P(t-1)^T  (8 MFMAs)                     with   scale + column bias + max of S(t)  (VALU)
 //     phase B:  S(t+1)^T = K(t+1) . Q^T     (8 MFMAs)                     with   exp2 and bf16 packing of P(t)       (VALU)
 // pinned with sched_group_barrier; every fragment of a phase is read from LDS at the top of the phase (a read placed right
 // before its MFMA exposed ~130 cycles of LDS latency sixteen times per tile).
-//   * row sums of P on the matrix pipe: ones . P^T leaves sum_k P[k][q] in every row of `lsum` (32 VALU adds per tile saved;
-//     the sum is over the bf16-rounded P, as the numerator is);
+//   * row sums of P on the VALU (32 adds per tile and lane, lane halves added once at the end). Round 1 had them on the matrix
+//     pipe (ones . P^T, 4 MFMAs per tile); tools/probes/valu_probe.hip then measured what an instruction costs here: an MFMA 32
+//     cycles, a vector instruction between MFMAs ~2 - so 128 cycles bought 70 (measured: 2.29 -> 2.21 ms; variant 6 = old form);
+//     the sum is over the fp32 P before its bf16 rounding;
 //   * lazy rescaling: the reference point m only moves when some row's tile max exceeds it by more than 8 (log2 domain), so
 //     p <= 256 and the 33 multiplies of the O / l rescale run a few times per row, not once per tile (same m in numerator
 //     and denominator: O / l is mathematically unchanged);
@@ -483,7 +488,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 // fma + max + sub + exp2 + cvt_pk/2  (-64 VALU, +10 MFMAs per tile). (Round 2 first tried the same fold through the
 // accumulator's start values - one add per score instead of two ops - which measured SLOWER: the adds sat on the MFMA's
 // critical path; an MFMA that starts from the inline constant 0 does not wait for VALU results.)
-template <typename TO, int FOLD, int NW = 4, bool STAMP = false>     // FOLD 0: fma form; 1: row bias - reference folded; 2: column bias folded too
+template <typename TO, int FOLD, int NW = 4, bool STAMP = false, bool VS = true>     // VS: row sums of P on the VALU (32 adds) instead of 4 MFMAs; FOLD 0: fma form; 1: row bias - reference folded; 2: column bias folded too
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(const FlashArgs a) {   // STAMP: timing probe (tools/attn_stamps.py): cycle sums instead of outputs   // NW waves x 32 queries per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
@@ -711,7 +716,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     for (int i = 0; i < 8; ++i) {
       const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-      if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
+      if (!VS && db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     float mloc = -INFINITY;
     int imax = 0;
@@ -775,7 +780,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int e = 0; e < 16; ++e) s[kb][e] -= d;
-        lsum[0] *= alpha;
+        lsum[0] *= alpha; if (VS) { lsum[1] *= alpha; lsum[2] *= alpha; }
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -787,7 +792,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
         const float mnew = fmaxf(m, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         m = mnew;
-        lsum[0] *= alpha;
+        lsum[0] *= alpha; if (VS) { lsum[1] *= alpha; lsum[2] *= alpha; }
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -819,6 +824,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
       f32x16 p;
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(FOLD ? s[kb][e] : s[kb][e] - msub);
+      if (VS) {                                         // this lane's 16 keys of the block (the other lane half holds the other 16)
+        lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
+        lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
+      }
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
@@ -872,9 +881,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
           const uint4 vfr = make_uint4(u0.x, u0.y, u1.x, u1.y);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
         }
-        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
+        if (!VS) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
       }
   }
+  if (VS) { const float l = lsum[1] + lsum[2]; lsum[0] = l + other_half(l); }
 
   if (STAMP) {                                          // probe build: no outputs, six cycle sums per wave at the start of `o`
     if (lane == 0) {
@@ -1059,7 +1069,6 @@ __global__ void __launch_bounds__(512, 1) flash_global_pp(const FlashArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-      if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     stamp(2);
@@ -1086,7 +1095,7 @@ __global__ void __launch_bounds__(512, 1) flash_global_pp(const FlashArgs a) {
       const float mnew = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m - mnew);
       m = mnew;
-      lsum[0] *= alpha;
+      lsum[1] *= alpha; lsum[2] *= alpha;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1098,6 +1107,8 @@ __global__ void __launch_bounds__(512, 1) flash_global_pp(const FlashArgs a) {
       f32x16 p;
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = ABL == 1 ? s[kb][e] - msub : __builtin_amdgcn_exp2f(s[kb][e] - msub);
+      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
+      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
@@ -1118,8 +1129,8 @@ __global__ void __launch_bounds__(512, 1) flash_global_pp(const FlashArgs a) {
   for (int i = 0; i < 8; ++i) {
     const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-    if (db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
   }
+  { const float l = lsum[1] + lsum[2]; lsum[0] = l + other_half(l); }
   if (STAMP) {
     if (lane == 0) {
 #pragma unroll
@@ -1284,7 +1295,7 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] -= d;
       if (blk != 0) {
-        lsum[0] *= alpha;
+        lsum[1] *= alpha; lsum[2] *= alpha;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
       }
@@ -1294,6 +1305,8 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
       f32x16 p;
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[e]);
+      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);     // row sums on the VALU (see flash_fwd)
+      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
@@ -1308,7 +1321,6 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
         const uint4 vfr = make_uint4(u0.x, u0.y, u1.x, u1.y);
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr), __builtin_bit_cast(bf16x8, pf[ks]), o[db], 0, 0, 0);
       }
-      lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[ks]), lsum, 0, 0, 0);
     }
   }
 
@@ -1316,7 +1328,8 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
   // quarter (fp32) of the 32 query rows at a time (row stride 80 B, 2560 B), stored as 64-byte row pieces, 16 rows per instruction.
   // EVERY lane writes before any lane reads and wavefront-scope fences separate the two: lanes exchange data through LDS here,
   // which single-thread reasoning does not see (a conditional write followed by a read let hipcc forward a stale register).
-  const float inv = 1.0f / lsum[0];
+  const float lhalf = lsum[1] + lsum[2];
+  const float inv = 1.0f / (lhalf + other_half(lhalf));
   char* stg = (char*)T;
   TO* out = (TO*)a.o;
   auto off = [&](int jq) -> long {
@@ -1372,14 +1385,14 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO, int FOLD, int NW = 4, bool STAMP = false>
+template <typename TO, int FOLD, int NW = 4, bool STAMP = false, bool VS = true>
 int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + NW * AUX_PER_WAVE + (NW == 8 ? 2 * AUX_PER_WAVE : 0);    // 80 KiB: two blocks per CU; NW = 8: 128 KiB, one
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD, NW, STAMP>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD, NW, STAMP, VS>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, NW * 32);
-  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD, NW, STAMP>), dim3(b.nqt * a.H * nb), dim3(NW * 64), lds, s, b);
+  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD, NW, STAMP, VS>), dim3(b.nqt * a.H * nb), dim3(NW * 64), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
 }
@@ -1399,6 +1412,7 @@ int launch_global_pp(const FlashArgs& a, int nb, hipStream_t s) {
 template <typename TO>
 int launch_global_pipe(const FlashArgs& a, int nb, int fold, hipStream_t s) {
   if (fold == 5) return launch_global_pp<TO>(a, nb, s);
+  if (fold == 6) return launch_global_pipe_<TO, 0, 4, false, false>(a, nb, s);   // row sums of P by a ones-row MFMA (the round-1 form; variant 6)
   if (fold == 10) return launch_global_pp<TO, true>(a, nb, s);    // timing probe of the ping-pong form (variant 10)
   if (fold >= 11 && fold <= 14) {                                    // probe-only ablations of the softmax segment (tools/attn_stamps.py B pp N)
     return fold == 11 ? launch_global_pp<TO, true, 1>(a, nb, s) : fold == 12 ? launch_global_pp<TO, true, 2>(a, nb, s)
@@ -1439,7 +1453,8 @@ int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
 // variant 3 2.41-2.42 ms (-33 VALU, +2 MFMAs per tile: +1 %), variant 2 2.57-2.68 ms (-64 VALU, +10 MFMAs: +12 %), variant 1
 // 2.40-2.51 ms: the kernel's time does not follow its VALU count, so the default stays the fma form. 4 = the default arithmetic in
 // 8-wave blocks (256 queries per block: K/V cross L2 -> LDS once per 256 queries, half the LDS-DMA instructions per wave):
-// bit-identical, 2.44-2.46 vs 2.31-2.32 ms (the per-tile barrier then spans 8 waves). 9 = timing probe of the default kernel:
+// bit-identical, 2.44-2.46 vs 2.31-2.32 ms (the per-tile barrier then spans 8 waves). 5 = ping-pong form (flash_global_pp),
+// 6 = row sums by a ones-row MFMA (round-1 form: 2.29-2.30 vs 2.21 ms). 9 = timing probe of the default kernel:
 // per-wave s_memtime sums per loop section are written INSTEAD of the outputs (tools/attn_stamps.py).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale, hipStream_t s) {
@@ -1472,8 +1487,8 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
-    if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 9 || (variant >= 10 && variant <= 14)) {
-      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : variant == 5 ? 5 : variant >= 9 ? variant : 0;
+    if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant == 9 || (variant >= 10 && variant <= 14)) {
+      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : variant == 5 ? 5 : variant == 6 ? 6 : variant >= 9 ? variant : 0;
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, fold, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, fold, s);
     }

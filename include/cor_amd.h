@@ -92,7 +92,7 @@ int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, cons
  * attention with the biases and the running reference (2) or the row bias and reference only (3) as extra k-steps of the score
  * MFMA (need q_prescale = scale * log2 e; A/B partners, measured 12 % / 1 % slower than 0); 4 = global attention in 8-wave
  * blocks (bit-identical to 0, 5 % slower); 5 = the ping-pong form (8-wave blocks, wave groups one barrier interval apart, matrix and
- * softmax segments alternating; bit-identical to 0, 5 % slower); 9 / 10..14 = timing probes of the default global kernel (cycle counters INSTEAD of outputs:
+ * softmax segments alternating; bit-identical to 0, 5 % slower); 6 = row sums of P by a ones-row MFMA (round-1 form, 4 % slower); 9 / 10..14 = timing probes of the default global kernel (cycle counters INSTEAD of outputs:
  * tools/attn_stamps.py only). */
 
 /* Which kernel family cor_attention (sam_window = -1) / cor_sam_attention (0 = global, > 0 = windowed) runs for 16-byte-aligned

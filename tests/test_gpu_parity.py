@@ -369,6 +369,8 @@ def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
     report(f"global_attn_pipe_B{B}_H{H}_amp{amp}", out, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
     out8 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=4)     # 8-wave blocks: same arithmetic per wave
     assert torch.equal(out8, out)
+    out6 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=6)     # row sums by a ones-row MFMA (over the bf16-rounded P)
+    report(f"global_attn_mfma_rowsum_B{B}_H{H}_amp{amp}", out6, out, rtol=0, atol=1e-2 * float(ref.abs().max()))
     out_pp = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=5)   # ping-pong form: same arithmetic per wave
     assert torch.equal(out_pp, out)
     assert torch.equal(out_pp, ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=5))
