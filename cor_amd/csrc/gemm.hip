@@ -67,8 +67,8 @@ constexpr int ROWB = 128;                              // bytes of K per tile ro
 // All bias / scale / residual loads of a slab are issued BEFORE any of them is consumed, from clamped (always valid)
 // addresses: with per-element predicated loads hipcc serialised "load, s_waitcnt vmcnt(0), use" 8-16 times per tile,
 // which cost ~7 us per tile (ablation in tools/gemm_ksweep.py) - more than the K loop at K = 768.
-template <int ACT> __device__ __forceinline__ float act_ct(float v) {
-  if constexpr (ACT == COR_ACT_GELU_ERF) return gelu_erf_f(v);
+template <int ACT, typename TO = float> __device__ __forceinline__ float act_ct(float v) {
+  if constexpr (ACT == COR_ACT_GELU_ERF) return sizeof(TO) == 2 ? gelu_erf_bf16out_f(v) : gelu_erf_f(v);   // bf16 outputs: polynomial erf (common.h)
   else if constexpr (ACT == COR_ACT_RELU) return fmaxf(v, 0.0f);
   else if constexpr (ACT == COR_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
   else if constexpr (ACT == COR_ACT_GELU_TANH) return gelu_tanh_f(v);
@@ -121,7 +121,7 @@ __device__ __forceinline__ void epilogue_vec_ct(const f32x16 (&acc)[MI][NJ], flo
       for (int q4 = 0; q4 < Q4; ++q4) {
         v[q4] = *(const f32x4*)(stg + row * WTN + cv * VW + 4 * q4) + bv[q4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT>(v[q4][q]);
+        for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT, TO>(v[q4][q]);
         v[q4] *= sv[q4];
         if constexpr (HAS_RES) v[q4] += res[j][q4];
       }
@@ -332,7 +332,7 @@ gemm_tile(const GemmArgs g) {   // <= 256 VGPR+AGPR (2 waves per SIMD) except th
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m >= g.M) continue;
-        float v = apply_act(acc[mi][nj][e] + bv, g.act) * sc;
+        float v = (sizeof(TO) == 2 && g.act == COR_ACT_GELU_ERF ? gelu_erf_bf16out_f(acc[mi][nj][e] + bv) : apply_act(acc[mi][nj][e] + bv, g.act)) * sc;   // same GELU as the vector epilogues
         if (g.residual) {
           const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
           v += g.residual[(long)rr * g.ldr + n];
@@ -396,7 +396,7 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
       for (int q4 = 0; q4 < Q4; ++q4) {
         v[q4] = *(const f32x4*)(stg + row * 32 + cv * VW + 4 * q4) + bv[q4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT>(v[q4][q]);
+        for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT, TO>(v[q4][q]);
         if constexpr (HAS_RES) v[q4] += res[blk % D][ps][q4];
       }
       // lanes outside C aim past num_records and are dropped by the buffer bounds check: no branch, fixed store count
@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, cons
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + ty + 8 * i;
     if (m >= M) continue;
-    float v = apply_act(acc[i] + bv, act) * sc;
+    float v = (sizeof(TO) == 2 && act == COR_ACT_GELU_ERF ? gelu_erf_bf16out_f(acc[i] + bv) : apply_act(acc[i] + bv, act)) * sc;
     if (residual) v += residual[(long)(res_row_mod > 0 ? m % res_row_mod : m) * ldr + n];
     st<TO>(C + (long)m * ldc + n, v);
   }
