@@ -616,6 +616,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
   const int nt = a.Tk / KT;
   const int srow = tid >> 3, sch = tid & 7;
   const int kswz = (sch ^ ((srow >> 1) & 7)) * 8;          // source chunk (elements) of the K copy; (32 + srow)>>1 & 7 is the same
+  // V: ds_read_b64_tr_b16 reads a 64-byte column window of key rows rho, rho+1, rho+2, rho+3 at once; rows are 128 B, so rows rho
+  // and rho+2 share their banks (2-way conflict on every V read: SQ_LDS_BANK_CONFLICT was 30 % of the kernel's LDS cycles). Rows
+  // with bit 1 set store their two 64-byte halves exchanged (source chunk ^ 4), the reader picks window db ^ bit 1 of its row.
+  const int vswz = (sch ^ (((srow >> 1) & 1) << 2)) * 8;
   const bf16_t* kv0 = kvbase + (long)srow * a.d3;           // row srow of tile 0; + 32*d3 for the second chunk
   // (NW = 8: 512 threads, one chunk each - half the LDS-DMA instructions per wave and tile, and K/V cross L2 -> LDS once per
   // 256 queries instead of once per 128)
@@ -626,7 +630,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     if (NW == 4) glds16(p0 + 32L * a.d3, d + 4096);
   };
   auto issue_v = [&](int t, int slot) {
-    const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + sch * 8;
+    const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + vswz;
     const unsigned d = lds0 + K_BYTES + slot * TILE_B + wofs;
     glds16(p0, d);
     if (NW == 4) glds16(p0 + 32L * a.d3, d + 4096);
@@ -643,6 +647,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
 #pragma unroll
   for (int c = 0; c < 4; ++c) kch[c] = r * 128 + (((2 * c + h) ^ sw) << 4);
   const int v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int v_trd[2] = {v_tr + ((lane >> 3) & 1) * 64, v_tr + (1 - ((lane >> 3) & 1)) * 64};   // window db of this lane's rows (halves exchanged where row bit 1 is set)
 
   f32x16 o[2], s[2], lsum;
 #pragma unroll
@@ -705,7 +710,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
-      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + db * 64 + v_tr;
+      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + v_trd[db];
       const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
       const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
       const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
@@ -874,7 +879,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
         const int krow = kb * 32 + ks * 16;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const char* vb = Vs + krow * 128 + db * 64 + v_tr;
+          const char* vb = Vs + krow * 128 + v_trd[db];
           const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
           const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
           const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
@@ -1198,7 +1203,8 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
       const bool isv = i >= 28;
       const int ii = isv ? i - 28 : i, kh = ii >> 1, hf = ii & 1, y = wy * 14 + kh;
       // K: source chunk swizzled for conflict-free ds_read_b128 (LDS row R = 16 kh + 8 hf + lane / 8: (R >> 1) & 7 = 4 hf + lane / 16)
-      const int chunk = isv ? sl : (sl ^ (4 * hf + (lane >> 4)));
+      // V: rows with bit 1 set store their 64-byte halves exchanged (conflict-free ds_read_b64_tr_b16, see flash_global_pipe): bit 1 of R = lane bit 4
+      const int chunk = isv ? (sl ^ (((lane >> 4) & 1) << 2)) : (sl ^ (4 * hf + (lane >> 4)));
       const long plane = (long)(isv ? 2 : 1) * a.H * 64 + chunk * 8;
       const bf16_t* src = (y < a.grid && okx[hf]) ? a.q + colp[hf] + (long)y * a.grid * a.d3 + plane : a.pad_row + head * 64 + plane;
       glds16(src, lds0 + (isv ? WIN_KV : 0) + ii * 1024);
@@ -1264,6 +1270,7 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
   // ---- 5. main loop: 7 blocks of 32 keys (two window rows each), no barrier
   const int sw = (r >> 1) & 7;
   const int k_rd = r * 128, v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int v_trd[2] = {v_tr + ((lane >> 3) & 1) * 64, v_tr + (1 - ((lane >> 3) & 1)) * 64};
   const int t_rd = (qh + 13) * 32 + r;                  // row table index of key row kh: t_rd - 32 * kh
   f32x16 o[2], lsum;
 #pragma unroll
@@ -1314,7 +1321,7 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const char* vb = Vt + (blk * 32 + ks * 16) * 128 + db * 64 + v_tr;
+        const char* vb = Vt + (blk * 32 + ks * 16) * 128 + v_trd[db];
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
         const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
