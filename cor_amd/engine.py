@@ -352,7 +352,7 @@ def _dec_attn(W, p, q, k, v, B, Tq, Tk, T, residual=None, out=None):
     return _lin(W, p + "out_proj.", o, F32, residual=residual, out=out)
 
 
-def mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=False, p="mask_decoder."):
+def mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=False, p="mask_decoder.", trace=None):
     """ref: lib/sam_model/mask_decoder.py:107-142 + transformer.py:62-106,151-182 + sam_with_sup_branch.py:96-100.
     emb_tokens fp32 [B*4096,256], feat fp32 [B,256] -> (final_masks [B,1,256,256], iou [B,4], best [B], masks_all|None)."""
     B = feat.shape[0]
@@ -385,6 +385,8 @@ def mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=False, p="m
         qpe = ops.add(queries, tokens, out_dtype=T)
         keys = _dec_attn(W, L + "cross_attn_image_to_token.", kpe, qpe, ops.cast(queries, T), B, Tk, Tq, T, residual=keys)
         keys = _ln(W, L + "norm4.", keys, 1e-5, F32)
+        if trace is not None:                                                              # per-stage parity tables (tests only)
+            trace[f"tokens_l{i}"], trace[f"keys_l{i}"] = queries, keys
     qpe = ops.add(queries, tokens, out_dtype=T)
     kpe = ops.add(keys, key_pe, out_dtype=T)
     keys_T = ops.cast(keys, T)
@@ -414,6 +416,8 @@ def mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=False, p="m
     best, hyper_sel = ops.iou_select(iou, hyper, k_off, ksel)
     final = ops.upscale_hyper(u1, w3, b3, hyper_sel, B, 2 * g, 2 * g, 1)
     masks_all = ops.upscale_hyper(u1, w3, b3, hyper, B, 2 * g, 2 * g, 4) if all_masks else None
+    if trace is not None:
+        trace.update(hs=hs, upscaled1=u1, hyper=hyper, iou=iou, masks_all=masks_all)
     return final, iou, best, masks_all, keys
 
 

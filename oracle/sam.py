@@ -137,7 +137,7 @@ def dense_pe(sd, p="prompt_encoder.", size=64):
     """Random-Fourier dense positional encoding.
     ref: lib/sam_model/my_prompt_encoder.py:62-71,191-211. -> [1,256,size,size]"""
     G = sd[p + "pe_layer.positional_encoding_gaussian_matrix"]           # [2,128]
-    c = (torch.arange(size, dtype=torch.float32) + 0.5) / size           # cumsum(ones) - 0.5, / size
+    c = (torch.arange(size, dtype=G.dtype) + 0.5) / size                 # cumsum(ones) - 0.5, / size (G's dtype: an fp64 state runs in fp64)
     xy = torch.stack([c[None, :].expand(size, size), c[:, None].expand(size, size)], dim=-1)  # (x, y)
     ang = 2 * math.pi * ((2 * xy - 1) @ G)                               # [size,size,128]
     pe = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
@@ -181,13 +181,15 @@ def two_way_block(sd, p, queries, keys, query_pe, key_pe, skip_first_layer_pe):
     return queries, keys
 
 
-def two_way_transformer(sd, p, src, pos, tokens):
+def two_way_transformer(sd, p, src, pos, tokens, trace=None):
     """ref: lib/sam_model/transformer.py:62-106. src,pos [B,256,h,w]; tokens [B,Nt,256]"""
     keys = src.flatten(2).permute(0, 2, 1)
     key_pe = pos.flatten(2).permute(0, 2, 1)
     queries = tokens
     for i in range(2):
         queries, keys = two_way_block(sd, f"{p}layers.{i}.", queries, keys, tokens, key_pe, i == 0)
+        if trace is not None:
+            trace[f"tokens_l{i}"], trace[f"keys_l{i}"] = queries, keys
     q, k = queries + tokens, keys + key_pe
     queries = _ln(sd, p + "norm_final_attn.", queries + dec_attention(sd, p + "final_attn_token_to_image.", q, k, keys), 1e-5)
     return queries, keys
@@ -210,23 +212,26 @@ def conv_transpose_2x2(x, w, b):
     return y + b
 
 
-def mask_decoder(sd, image_embeddings, image_pe, sparse, dense, multimask_output, p="mask_decoder."):
+def mask_decoder(sd, image_embeddings, image_pe, sparse, dense, multimask_output, p="mask_decoder.", trace=None):
     """ref: lib/sam_model/mask_decoder.py:66-142. Returns (masks [B,C,256,256], iou [B,C], keys [B,4096,256])."""
     B = image_embeddings.shape[0]
     out_tok = torch.cat([sd[p + "iou_token.weight"], sd[p + "mask_tokens.weight"]], 0)   # [5,256]
     tokens = torch.cat([out_tok.unsqueeze(0).expand(B, -1, -1), sparse], dim=1)           # [B,6,256]
     src = image_embeddings + dense
     pos = image_pe.expand(B, -1, -1, -1)
-    hs, keys = two_way_transformer(sd, p + "transformer.", src, pos, tokens)
+    hs, keys = two_way_transformer(sd, p + "transformer.", src, pos, tokens, trace)
     iou_tok, mask_tok = hs[:, 0], hs[:, 1:5]
     # :132  src.transpose(1,2).view(B,-1,64,64): keys [B,4096,256] seen as NCHW == channels-last tokens [B,64,64,256]
     g = int(math.isqrt(keys.shape[1]))
     x = keys.reshape(B, g, g, -1)
     x = conv_transpose_2x2(x, sd[p + "output_upscaling.0.weight"], sd[p + "output_upscaling.0.bias"])
     x = gelu_erf(_ln(sd, p + "output_upscaling.1.", x, 1e-6))
+    u1 = x
     x = gelu_erf(conv_transpose_2x2(x, sd[p + "output_upscaling.3.weight"], sd[p + "output_upscaling.3.bias"]))
     hyper = torch.stack([_mlp3(sd, f"{p}output_hypernetworks_mlps.{i}.", mask_tok[:, i]) for i in range(4)], 1)
     masks = torch.einsum("bkc,bhwc->bkhw", hyper, x)                     # [B,4,256,256]
     iou = _mlp3(sd, p + "iou_prediction_head.", iou_tok)
+    if trace is not None:                                                # per-stage parity tables (tests)
+        trace.update(hs=hs, upscaled1=u1, hyper=hyper, iou=iou, masks_all=masks)
     sl = slice(1, None) if multimask_output else slice(0, 1)             # :97-102
     return masks[:, sl], iou[:, sl], keys

@@ -20,11 +20,11 @@ def bilinear_resize(x, oh, ow):
         return x
 
     def taps(n_in, n_out):
-        s = (torch.arange(n_out, dtype=torch.float32) + 0.5) * (n_in / n_out) - 0.5
+        s = (torch.arange(n_out, dtype=x.dtype) + 0.5) * (n_in / n_out) - 0.5      # x's dtype: an fp64 evaluation stays fp64
         s = s.clamp(min=0)
         i0 = s.floor().long().clamp(max=n_in - 1)
         i1 = (i0 + 1).clamp(max=n_in - 1)
-        return i0, i1, s - i0.float()
+        return i0, i1, s - i0.to(x.dtype)
 
     y0, y1, wy = taps(H, oh)
     x0, x1, wx = taps(W, ow)
@@ -62,7 +62,7 @@ def mask_adapter_maps(sd, p, dense, mask):
     """GenerateMaskAdapterMap.forward with one mask per sample.
     ref: lib/support_model/mask_adapter.py:144-179 (mask_downscaling :128-142). dense [B,512,H,W], mask [B,1,H,W]"""
     H, W = dense.shape[-2:]
-    m = bilinear_resize(mask.float(), 4 * H, 4 * W)
+    m = bilinear_resize(mask.to(dense.dtype), 4 * H, 4 * W)
     md = p + "mask_downscaling."
     m = F.conv2d(m, sd[md + "0.weight"], sd[md + "0.bias"], stride=2, padding=1)
     m = gelu_erf(_ln_cf(sd, md + "1.", m))
