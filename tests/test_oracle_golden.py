@@ -194,3 +194,19 @@ def test_mask_resize_restatement_vs_pillow_and_torch():
         if oh >= ih and ow >= iw:
             pil = np.asarray(Image.fromarray(x[0, 0].numpy(), mode="F").resize((ow, oh), Image.BILINEAR))
             assert float(np.abs(got[0, 0].numpy() - pil).max()) <= 3e-5, (ih, iw, oh, ow)   # Pillow computes its weights in double
+
+
+@pytest.mark.parametrize("pooling", ["MaskAdapterPooling", "MaskedPooling"])
+def test_reference_autocast_fixture_is_the_same_model_in_bf16(pooling):
+    """tests/golden/toplevel_autocast_bf16_*.npz = the reference's top-level forward under torch.autocast("cpu", bf16)
+    (tools/make_golden.py gen_toplevel_autocast) on the parameters / inputs of toplevel_*.npz: the same outputs up to bf16-level
+    error (its recorded full-tensor error statistics agree with what the sub-sampled arrays show), i.e. a usable yardstick for
+    the HIP bf16 mode's budgets."""
+    g, ga = load(f"toplevel_{pooling}"), load(f"toplevel_autocast_bf16_{pooling}")
+    assert int(g["seed_params"]) == int(ga["seed_params"]) and int(g["seed_inputs"]) == int(ga["seed_inputs"])
+    for key, stat in (("emb", "emb_rel_l2"), ("masks_1", "masks_rel_l2_1"), ("masks_0", "masks_rel_l2_0"), ("feat", "feat_rel_l2")):
+        a, b = torch.from_numpy(ga[key]).double(), torch.from_numpy(g[key]).double()
+        rel = float((a - b).norm() / b.norm())
+        assert 1e-4 < rel < 0.1, (key, rel)                       # bf16-level, not fp32-level and not garbage
+        # (the arrays are every 4th pixel = ONE phase of the decoder's 4x4 up-sampling pattern: a biased sample of the full-tensor figure)
+        assert 0.5 * float(ga[stat]) <= rel <= 2.0 * float(ga[stat]), (key, rel, float(ga[stat]))

@@ -280,8 +280,53 @@ def gen_toplevel():
     save("state_dict_keys_sam_base", keys=np.array(ref_keys))
 
 
+def gen_toplevel_autocast():
+    """(vii-b) the SAME top-level model / parameters / inputs as gen_toplevel, run the way the reference runs inference:
+    under bf16 autocast (utils/vailder.py:416 `with accelerator.autocast():`, config/vaild_config/vaild_a.yaml:4
+    mixed_precision bf16) - here torch.autocast("cpu", dtype=torch.bfloat16), the only autocast this container can execute.
+    What is committed is the reference's own bf16-mode ERROR against its fp32 outputs (the toplevel_* fixtures): the yardstick
+    the HIP bf16 mode's error budget is tied to (tests/test_gpu_parity.py::test_full_depth_bf16_vs_reference_golden_with_counts)."""
+    gcfg = dict(ocfg.siglip_cfg("ViT-B-16-SigLIP-384"), depth=2, t_depth=2, vocab=512)
+    stub = types.ModuleType("open_clip")
+    stub.create_model_and_transforms = lambda name, pretrained=None: (_StandInClip(gcfg), None, None)
+    stub.get_tokenizer = lambda name: None
+    sys.modules["open_clip"] = stub
+    from lib.build_model import build_model_with_query_support_feat
+    for pooling in ("MaskAdapterPooling", "MaskedPooling"):
+        model = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, pooling).eval()
+        spec = ocfg.model_spec("sam_base", "ViT-B-16-SigLIP-384", pooling)
+        spec = {k: v for k, v in spec.items() if "attn_pool" not in k and not (".siglip." in k and any(
+            f".blocks.{i}." in k or f".resblocks.{i}." in k for i in range(2, 12)))}
+        spec["support_branch.siglip.model.text.token_embedding.weight"] = (512, 768)
+        model.load_state_dict(ocfg.random_state(spec, seed=171), strict=True)
+        inp = make_inputs(172, q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 512), mask=("mask", 1, 384))
+        out = dict(seed_params=171, seed_inputs=172)
+        for mm in (True, False):
+            kw = dict(query_image_inputs=inp["q"], support_image_inputs=inp["s"], change_text_inputs=inp["text"],
+                      support_mask_inputs=inp["mask"], multimask_output=mm)
+            m32, e32, f32_ = model(**kw)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                m16, e16, f16_ = model(**kw)
+            m16, e16, f16_ = m16.float(), e16.float(), f16_.float()
+            rel = lambda a, b: float((a - b).norm() / b.norm())
+            out[f"masks_{int(mm)}"] = strided(m16, 4)
+            out[f"masks_rel_l2_{int(mm)}"] = rel(m16, m32)
+            out[f"masks_max_abs_{int(mm)}"] = float((m16 - m32).abs().max())
+            out[f"masks_sign_flips_{int(mm)}"] = int(((m16 > 0) != (m32 > 0)).sum())
+            out[f"masks_sign_flips_strided_{int(mm)}"] = int(((m16 > 0) != (m32 > 0))[..., ::4, ::4].sum())
+            out["emb"] = strided(e16, 4)
+            out["emb_rel_l2"] = rel(e16, e32)
+            out["emb_max_abs"] = float((e16 - e32).abs().max())
+            out["feat"] = f16_.numpy()
+            out["feat_rel_l2"] = rel(f16_, f32_)
+            out["feat_max_abs"] = float((f16_ - f32_).abs().max())
+            print(f"  {pooling} multimask={mm}: autocast-bf16 vs fp32 of the reference: emb rel-L2 {out['emb_rel_l2']:.3e}, "
+                  f"masks rel-L2 {out[f'masks_rel_l2_{int(mm)}']:.3e}, sign flips {out[f'masks_sign_flips_{int(mm)}']}/65536, feat rel-L2 {out['feat_rel_l2']:.3e}")
+        save(f"toplevel_autocast_bf16_{pooling}", **out)
+
+
 GENS = dict(attention=gen_sam_attention, block=gen_sam_block, encoder=gen_sam_encoder, decoder=gen_decoder,
-            pooling=gen_mask_pooling, fuse=gen_fuse, region=gen_region, toplevel=gen_toplevel)
+            pooling=gen_mask_pooling, fuse=gen_fuse, region=gen_region, toplevel=gen_toplevel, toplevel_autocast=gen_toplevel_autocast)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
