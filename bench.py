@@ -12,8 +12,9 @@ per-shard top-k lists go to rank 0 in one gather and are merged on the host. A "
 The timed steps replay the forward as one captured hipGraph (`config.launch`; --graph 0 = eager launches); the GEMM events behind
 `roofline` then come from an eager re-run of the same steps right after the timed region (`roofline.events`).
 One JSON line on rank 0. `roofline` is for the dominant kernel (the bf16 MFMA GEMM); `cpu_baseline` is the CPU oracle
-timed on the host cores on a bounded sample (3 triplets) at N=1; `recall_at_1` (outside the timed region) compares the
-bf16 HIP pipeline's top-1 with the fp32 CPU oracle's on those triplets against the same gallery with planted positives.
+timed on the host cores on a bounded sample (3 triplets) at N=1; `recall` (outside the timed region) compares the benchmarked
+pipeline's top-k over ALL 32 queries with the exact-fp32 HIP mode's (and the fp32 CPU oracle's on the 3 CPU triplets) against the
+same gallery with one planted positive per query; inputs are per-sample texture tiles so that the 32 queries are not collinear.
 """
 from __future__ import annotations
 
@@ -67,12 +68,14 @@ def gemm_source_id():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev):
+def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast):
     """(1) cpu_baseline: the CPU oracle (fp32 PyTorch-CPU restatement of the reference, pinned by tests/golden; kind "port")
     on the first NB_CPU triplets of the SAME synthetic batch with the SAME weights + similarity vs the same gallery.
-    (2) recall_at_1: positives are planted for those triplets from the oracle's fp32 query features
-    (gallery[pi(b)] = normalize(q_b + 0.1 N(0,1))); the bf16 HIP pipeline (forward + cor_similarity_topk on the bf16 gallery)
-    must return the same top-1 as the fp32 CPU oracle (fp32 features, fp32 product on the same stored rows)."""
+    (2) recall, over ALL queries of the batch, outside every timed region. Reference features = the exact-fp32 HIP
+    mode (pinned to the reference's goldens at 1e-5; the CPU oracle cannot run 32 full-size triplets in seconds) - and, for
+    the first NB_CPU queries, the fp32 CPU oracle itself. Positives are planted from the reference features
+    (gallery[pi(b)] = normalize(q_b + 0.1 N(0,1))); the benchmarked pipeline (feat_fast: the bf16 forward's features, then
+    cor_similarity_topk on the bf16 gallery) must return the reference's top-1 (fp32 features, fp32 CPU product on the same rows)."""
     from oracle import model as omodel, retrieval as oret
     from cor_amd import retrieval
     ncores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives one GPU's share of the host: 16 cores
@@ -87,24 +90,37 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev):
         oret.similarity_topk(feat[:, 0], G32, args.topk)
     dt = time.perf_counter() - t0
     cpu = dict(value=NB_CPU / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
-               sample=f"{NB_CPU} triplets in one batch ({args.sam}+{args.siglip} fp32 forward + {G32.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s")
-    # ---- recall (outside every timed region)
-    q_ref = feat[:, 0].float()
+               sample=f"{NB_CPU} triplets in one batch ({args.sam}+{args.siglip} fp32 forward + {G32.shape[0]}-row similarity/top-k), 1 run, {dt:.1f} s; "
+                      "SURVEY 8d's protocol (B = 1 and 4, 1 warm-up + 3 timed) would take minutes of CPU time: bounded to one un-warmed batch")
+    q_cpu = feat[:, 0].float()
+    # ---- reference features of the whole batch: exact-fp32 HIP mode
+    B = feat_fast.shape[0]
+    fast_dtype = model.compute_dtype
+    model.compute_dtype = torch.float32
+    with torch.no_grad():
+        q_ref = torch.cat([model(**{k: v[i:i + 8] for k, v in batch.items()}, multimask_output=True)[2][:, 0] for i in range(0, B, 8)]).float().cpu()
+    model.compute_dtype = fast_dtype
+    cosm = q_ref.double() @ q_ref.double().T - 2 * torch.eye(B, dtype=torch.float64)
     gen = torch.Generator(device="cpu").manual_seed(4321)
-    where = torch.arange(NB_CPU) * 7919 + 13
+    where = torch.arange(B) * 2999 + 13                                              # < 100000 for B <= 33
     G = gallery_rows_cpu.clone()
     G[where] = torch.nn.functional.normalize(q_ref + 0.1 * torch.randn(q_ref.shape, generator=gen), dim=-1)
     G = G.to(torch.bfloat16)
-    rs, ri = oret.similarity_topk(q_ref, G.float(), args.topk)                       # fp32 CPU oracle end to end
-    with torch.no_grad():
-        _, _, f_gpu = model(**{k: v[:NB_CPU] for k, v in batch.items()}, multimask_output=True)
-    gs, gi = retrieval.GalleryShard(G.to(dev), 0).search(f_gpu[:, 0], args.topk)
+    rs, ri = oret.similarity_topk(q_ref, G.float(), args.topk)                       # fp32 reference features, fp32 CPU product
+    _, ri_cpu = oret.similarity_topk(q_cpu, G.float(), args.topk)                    # fp32 CPU oracle end to end (first NB_CPU queries)
+    gs, gi = retrieval.GalleryShard(G.to(dev), 0).search(feat_fast.float().contiguous(), args.topk)
     gi = gi.cpu()
-    rec = dict(recall_at_1=float((gi[:, 0] == ri[:, 0]).float().mean()), queries=NB_CPU,
+    rec = dict(recall_at_1=float((gi[:, 0] == ri[:, 0]).float().mean()), queries=B,
                recall_at_1_planted=float((gi[:, 0] == where).float().mean()), oracle_recall_at_1_planted=float((ri[:, 0] == where).float().mean()),
                topk_index_mismatches=int((gi != ri).sum()), topk_entries=int(ri.numel()),
-               feature_max_abs_err=float((f_gpu[:, 0].cpu() - q_ref).abs().max()),
-               definition="top-1 of the bf16 HIP pipeline == top-1 of the fp32 CPU oracle (same weights, inputs, gallery with planted positives)")
+               max_pairwise_cos=float(cosm.max()), feature_max_abs_err=float((feat_fast.float().cpu() - q_ref).abs().max()),
+               cpu_oracle_queries=NB_CPU, cpu_oracle_recall_at_1=float((gi[:NB_CPU, 0] == ri_cpu[:, 0]).float().mean()),
+               cpu_oracle_recall_at_1_planted=float((ri_cpu[:, 0] == where[:NB_CPU]).float().mean()),
+               cpu_oracle_vs_fp32_hip_feature_max_abs_err=float((q_cpu - q_ref[:NB_CPU]).abs().max()),
+               definition="top-1 of the benchmarked pipeline (bf16 forward + cor_similarity_topk, bf16 gallery) == top-1 of the reference (exact-fp32 HIP "
+                          "features, pinned to the reference's goldens; fp32 CPU product) over all queries, gallery with one planted positive per query; "
+                          "cpu_oracle_*: the same against the fp32 CPU oracle's own features for the first queries; inputs: per-sample texture tiles, "
+                          "support-head biases zeroed (utils.synthetic_batch(structured=True), utils.zero_support_head_biases: de-collinearised queries)")
     return cpu, rec
 
 
@@ -129,10 +145,11 @@ def main():
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = build_model_with_query_support_feat(args.sam, args.siglip, None, None, "MaskAdapterPooling")
     utils.randomize_parameters(model, seed=0)
+    utils.zero_support_head_biases(model)               # with structured inputs: 32 distinct query embeddings instead of 32 collinear ones
     model = model.to(dev).eval()
     model.compute_dtype = T
     B = args.batch
-    batch = utils.synthetic_batch(B, dev, seed=rank)
+    batch = utils.synthetic_batch(B, dev, seed=rank, structured=True)
     Gtot = args.gallery
     lo, hi = retrieval.shard_bounds(Gtot, world, rank)
     gen = torch.Generator(device="cpu").manual_seed(1234)
@@ -238,7 +255,9 @@ def main():
         res["config"]["launch"] = launch_mode
         res["roofline"]["events"] = events_from
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], rec = cpu_baseline_and_recall(args, model, batch, rows_all, dev)
+            with torch.no_grad():                        # the benchmarked pipeline's features of this batch (graph replay when --graph 1)
+                feat_fast = (graphed(**batch) if graphed is not None else model(**batch, multimask_output=True))[2][:, 0].clone()
+            res["cpu_baseline"], rec = cpu_baseline_and_recall(args, model, batch, rows_all, dev, feat_fast)
             res["recall_at_1"] = rec["recall_at_1"]
             res["recall"] = rec
         print(json.dumps(res), flush=True)

@@ -35,11 +35,20 @@ def randomize_parameters(model: torch.nn.Module, seed: int = 0) -> None:
         model.invalidate_packed()
 
 
-def synthetic_batch(B: int, device, seed: int = 0, vocab: int = 32000):
-    """SURVEY 8d inputs: N(0,1) images at model size, 4-20 random token ids then pad id 1, one rectangle mask."""
+def synthetic_batch(B: int, device, seed: int = 0, vocab: int = 32000, structured: bool = False):
+    """SURVEY 8d inputs: N(0,1) images at model size, 4-20 random token ids then pad id 1, one rectangle mask.
+    structured: every image = a per-sample random 16x16x3 texture tile (N(0,1)) repeated over the image + 0.3 N(0,1). Pure-noise
+    images all look alike to a random-init network (the 32 query features of a batch come out 0.9997 collinear, so a planted-
+    positive Recall@1 is a coin flip; low-frequency colour fields only vary in ~3 dimensions: 20 of 496 pairs above cos 0.9).
+    A per-sample texture moves every patch embedding in its own 768-dimensional direction: with the support head's additive
+    constants zeroed (zero_support_head_biases) bench.py's 32 features are pairwise below cos 0.6 and Recall@1 means something."""
     gen = torch.Generator(device="cpu").manual_seed(seed)
     q = torch.randn((B, 3, 1024, 1024), generator=gen)
     s = torch.randn((B, 3, 384, 384), generator=gen)
+    if structured:
+        for img in (q, s):
+            tile = torch.randn((B, 3, 16, 16), generator=gen)
+            img.mul_(0.3).add_(tile.repeat(1, 1, img.shape[-2] // 16, img.shape[-1] // 16))
     text = torch.ones((B, 64), dtype=torch.int64)
     mask = torch.zeros((B, 1, 384, 384))
     for b in range(B):
@@ -51,6 +60,22 @@ def synthetic_batch(B: int, device, seed: int = 0, vocab: int = 32000):
         mask[b, 0, y0:y0 + h, x0:x0 + w] = 1.0
     return dict(query_image_inputs=q.to(device), support_image_inputs=s.to(device), change_text_inputs=text.to(device),
                 support_mask_inputs=mask.to(device))
+
+
+def zero_support_head_biases(model: torch.nn.Module) -> None:
+    """Benchmark-only companion of synthetic_batch(structured=True): zero the additive constants between the SigLIP towers and
+    comb_support_feat (final norms' beta, text projection bias, every bias / LayerNorm beta of the pooling, fusion and projection
+    head). With random-init weights those constants are a component COMMON to every sample's feature and dominate it; removing
+    them costs nothing (same kernels, same shapes) and lets different inputs give different query embeddings."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            head = name.startswith("support_branch.") and ".siglip." not in name
+            tower_end = name in ("support_branch.siglip.model.visual.trunk.norm.bias", "support_branch.siglip.model.text.ln_final.bias",
+                                 "support_branch.siglip.model.text.text_projection.bias")
+            if (head or tower_end) and name.endswith("bias"):
+                p.zero_()
+    if hasattr(model, "invalidate_packed"):
+        model.invalidate_packed()
 
 
 class DoubleBufferedH2D:
