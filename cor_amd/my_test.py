@@ -58,8 +58,11 @@ def main(argv=None):
     opt = load_config(args.config)
     accelerator = None
     if args.accelerate:
+        # ref: my_test.py:56 `Accelerator()`: precision comes from the `accelerate launch --config_file` YAML (config/vaild_config/
+        # vaild_a.yaml:4 mixed_precision: bf16). Started without that launcher, the YAML key `mixed_precision` of THIS config plays its part.
         from accelerate import Accelerator
-        accelerator = Accelerator()
+        mp = getattr(opt, "mixed_precision", None)
+        accelerator = Accelerator(mixed_precision=mp) if mp and "ACCELERATE_MIXED_PRECISION" not in os.environ else Accelerator()
     is_main = accelerator is None or accelerator.is_main_process
     set_seed(0)
     os.makedirs(opt.vaild_model_save_path, exist_ok=True)

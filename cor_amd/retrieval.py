@@ -55,6 +55,9 @@ class GalleryShard:
     def search(self, queries: torch.Tensor, k: int):
         """queries f32[Bq,C] (unit-norm) -> (scores f32[Bq,k], global idx i64[Bq,k]) on the GPU."""
         q = queries.reshape(-1, queries.shape[-1]).to(self.rows.device, torch.float32).contiguous()
+        if self.rows.shape[0] == 0:                  # an empty shard (more ranks than gallery rows): all-missing lists, like Ng < k
+            return (torch.full((q.shape[0], k), float("-inf"), device=q.device),
+                    torch.full((q.shape[0], k), -1, dtype=torch.int64, device=q.device))
         with torch.cuda.device(self.rows.device):
             return ops.similarity_topk(q, self.rows, k, g_offset=self.offset)
 
@@ -83,12 +86,16 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
 
     Two collectives in all, as BASELINE.json's north_star describes it:
       1. ONE all-gather of the query embeddings over RCCL/xGMI (<= 64 KB per rank: latency-bound). The payload is a
-         fixed-size block [max_local + 1, C]: rows 0..B_local-1 are the queries, the last row carries B_local, so a ragged
-         last batch (B_local differing between ranks) is legal as long as every rank passes the same `max_local`
+         fixed-size block [max_local + 1, C]: rows 0..B_local-1 are the queries, the rest zeros, the last row carries B_local,
+         so a ragged last batch (B_local differing between ranks) is legal as long as every rank passes the same `max_local`
          (a configuration constant, e.g. the loader's batch size; default: this rank's B_local, i.e. equal batches);
-      2. each rank scores ALL queries against its shard (cor_similarity_topk) and the packed per-shard lists
-         ([B_total,k,3] int32 = 12 B per entry) go to rank `dst` in ONE gather, where they are merged ONCE on the host
-         by (score desc, global index asc). dst=None: all-gather instead, every rank merges (the round-1 behaviour).
+      2. each rank scores ALL world * max_local query SLOTS against its shard (cor_similarity_topk; the slots beyond a rank's
+         count are zero rows whose results are dropped at the end - nothing is compacted, so the counts never have to reach
+         the host in the middle of the step) and the packed per-shard lists ([slots,k,3] int32 = 12 B per entry) go to rank
+         `dst` in ONE gather, where they are merged ONCE on the host by (score desc, global index asc). dst=None: all-gather
+         instead, every rank merges.
+    Host synchronisation: none on the ranks that return (None, None); on `dst` exactly one device-to-host copy at the very
+    end (lists + per-rank counts in one buffer) - the next step's forward can be enqueued before it is awaited.
     Returns (scores f32[B_total,k], idx i64[B_total,k]) CPU tensors, queries ordered by rank, on rank `dst` (every rank
     for dst=None); (None, None) on the other ranks."""
     import torch.distributed as dist
@@ -110,11 +117,8 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
     allb = torch.empty((world * (cap + 1), C), dtype=torch.float32, device=cdev)
     dist.all_gather_into_tensor(allb, block, group=group)        # collective 1 (RCCL over xGMI)
     allb = allb.view(world, cap + 1, C)
-    counts = [int(c) for c in allb[:, cap, 0].tolist()]          # (the result lists go to the host anyway)
-    if any(c < 0 or c > cap for c in counts):
-        raise RuntimeError(f"distributed_search: inconsistent per-rank query counts {counts} for max_local={cap}")
-    allq = torch.cat([allb[r, :counts[r]] for r in range(world)], dim=0).to(dev)
-    s, i = shard.search(allq, k)                                 # local shard vs ALL queries
+    slots = allb[:, :cap].reshape(world * cap, C).to(dev)        # every slot is scored; counts stay where they are
+    s, i = shard.search(slots, k)                                # local shard vs ALL query slots
     packed = _pack_lists(s, i).to(cdev)
     if dst is None:
         parts = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=torch.int32, device=cdev)
@@ -126,8 +130,15 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
         if rank != dst:
             return None, None
         parts = torch.stack(glist, dim=0)
-    ps, pi = _unpack_lists(parts.cpu())
-    return merge_topk_host(list(ps), list(pi), k)
+    # the ONE device-to-host copy: lists of all shards + the per-rank counts (as int32) in one buffer
+    counts_i = allb[:, cap, 0].to(torch.int32)
+    host = torch.cat([parts.reshape(-1), counts_i.to(parts.device)]).cpu()
+    counts = host[-world:].tolist()
+    if any(c < 0 or c > cap for c in counts):
+        raise RuntimeError(f"distributed_search: inconsistent per-rank query counts {counts} for max_local={cap}")
+    ps, pi = _unpack_lists(host[:-world].view(parts.shape))      # [world(shard), world*cap(slot), k]
+    keep = torch.cat([torch.arange(r * cap, r * cap + counts[r]) for r in range(world)])
+    return merge_topk_host(list(ps[:, keep]), list(pi[:, keep]), k)
 
 
 @torch.no_grad()

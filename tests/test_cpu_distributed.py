@@ -17,7 +17,9 @@ class _OracleShard:
 
     def search(self, queries, k):
         from oracle import retrieval as oret
-        s, i = oret.similarity_topk(queries, self.rows, k)
+        if self.rows.shape[0] == 0:                                   # empty shard (more ranks than gallery rows): all-missing lists
+            return torch.full((queries.shape[0], k), float("-inf")), torch.full((queries.shape[0], k), -1, dtype=torch.int64)
+        s, i = oret.similarity_topk(queries, self.rows, min(k, self.rows.shape[0]))
         i = i + self.offset
         if s.shape[1] < k:       # pad like the kernel does (score -inf, index -1)
             pad = k - s.shape[1]
@@ -65,6 +67,25 @@ def test_pack_unpack_lists_roundtrip():
     i = torch.tensor([[5, -1], [2 ** 40 + 3, -2]], dtype=torch.int64)
     s2, i2 = retrieval._unpack_lists(retrieval._pack_lists(s, i))
     assert torch.equal(s.view(torch.int32), s2.view(torch.int32)) and torch.equal(i, i2)
+
+
+@pytest.mark.parametrize("Ng,k,split", [(1000, 10, (0, 2, 3, 5, 6)), (3, 4, (0, 2, 4, 6, 6)), (9, 10, (0, 6, 6, 6, 6))])
+def test_distributed_search_world4_gloo_with_empty_shards_and_ranks(Ng, k, split):
+    """Four ranks: ragged query counts (a rank with NO queries), and galleries so small that the last shard(s) are EMPTY
+    (shard_bounds gives rank 3 rows [3,3) of a 3-row gallery): empty shards contribute (-inf, -1) lists and the merge must
+    still equal the single-process oracle."""
+    from oracle import retrieval as oret
+    gen = torch.Generator().manual_seed(1)
+    G = torch.nn.functional.normalize(torch.randn((Ng, 256), generator=gen), dim=-1)
+    Q = torch.nn.functional.normalize(torch.randn((6, 256), generator=gen), dim=-1)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(4, _free_port(), G, Q, k, split, out), nprocs=4, join=True)
+    rs, ri = oret.similarity_topk(Q, G, min(k, Ng))
+    kk = min(k, Ng)
+    assert torch.equal(out["i"][:, :kk], ri) and torch.allclose(out["s"][:, :kk], rs, atol=1e-6)   # (shard-sized vs full-size CPU matmuls)
+    if k > Ng:
+        assert (out["i"][:, Ng:] == -1).all()
 
 
 @pytest.mark.parametrize("Ng,k,split", [(1000, 10, (0, 3, 6)), (7, 8, (0, 3, 6)), (1000, 10, (0, 4, 6)), (300, 5, (0, 6, 6))])

@@ -138,3 +138,62 @@ def test_siglip_cfg_per_tower_gelu():
     assert g["v_gelu"] == "erf" and g["t_gelu"] == "tanh"
     with pytest.raises(ValueError):
         config.normalize_siglip_cfg(dict(v_gelu="swish"))
+
+
+def test_lib_alias_resolves_the_reference_imports():
+    """`sys.modules["lib"] = cor_amd.lib` lets the reference's own import lines resolve unchanged
+    (my_test.py:14 `from lib.build_model import build_model_with_query_support_feat`; lib/build_model.py:4-10 sub-module names)."""
+    import importlib, sys
+    import cor_amd.lib as L
+    saved = {k: v for k, v in sys.modules.items() if k == "lib" or k.startswith("lib.")}
+    try:
+        sys.modules["lib"] = L
+        for sub in ("build_model", "sam_with_sup_branch", "support_branch", "sam_model", "support_model", "sam_model.image_encoder",
+                    "sam_model.mask_decoder", "sam_model.transformer", "sam_model.my_prompt_encoder", "sam_model.common",
+                    "support_model.mask_adapter", "support_model.cir_feature_fuse", "support_model.siglip_openclip"):
+            sys.modules["lib." + sub] = importlib.import_module("cor_amd.lib." + sub)
+        ns = {}
+        exec("from lib.build_model import build_model_with_query_support_feat\n"
+             "from lib.sam_with_sup_branch import CirSegModelWithQuerySupportFeat\n"
+             "from lib.sam_model.image_encoder import ImageEncoderViT\n"
+             "from lib.support_model.mask_adapter import MaskAdapterPooling, MaskedPooling", ns)
+        from cor_amd.lib.build_model import build_model_with_query_support_feat as ours
+        assert ns["build_model_with_query_support_feat"] is ours
+        with pytest.raises(ValueError):
+            ns["build_model_with_query_support_feat"](sam_model="sam_tiny")                   # lib/build_model.py:49
+    finally:
+        for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_siglip_tokenizer_with_a_locally_trained_sentencepiece_model(tmp_path):
+    """cor_amd.tokenizer.siglip_tokenizer (utils/dataloader.py:296 -> open_clip.get_tokenizer -> SigLipTokenizer): the real c4-en
+    vocabulary is not available offline, so the wrapper's own logic is exercised on a tiny sentencepiece model trained here with the
+    T5 special-token layout (<pad> 0, </s> 1, <unk> 2): canonicalisation (lower-case, punctuation stripped, whitespace collapsed),
+    EOS id 1 appended, padding WITH id 1 (SigLIP sets pad = eos, so the pooled last position is always id 1), fixed length 64,
+    truncation to 63 pieces + EOS."""
+    import sentencepiece as spm
+    from cor_amd import tokenizer
+    words = ["make", "the", "cat", "dog", "larger", "smaller", "red", "blue", "please", "number", "left", "right", "remove", "add", "a", "of"]
+    rng = np.random.default_rng(0)
+    corpus = tmp_path / "corpus.txt"
+    with open(corpus, "w") as f:
+        for _ in range(2000):
+            f.write(" ".join(rng.choice(words, size=int(rng.integers(3, 12)))) + "\n")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "tiny"), vocab_size=48, model_type="unigram", hard_vocab_limit=False,
+                                   pad_id=0, eos_id=1, unk_id=2, bos_id=-1, minloglevel=2)
+    sp = spm.SentencePieceProcessor(model_file=str(tmp_path / "tiny.model"))
+    tok = tokenizer.siglip_tokenizer(str(tmp_path / "tiny.model"))
+    t = tok("Make the CAT   larger, please!")
+    assert t.dtype == torch.int64 and t.shape == (64,)
+    ids = sp.encode("make the cat larger please")
+    n = len(ids)
+    assert t[:n].tolist() == ids and int(t[n]) == 1 and bool((t[n:] == 1).all())          # pieces, EOS, pad = 1
+    assert torch.equal(t, tok("make the cat larger please"))                                # canonicalisation is what made them equal
+    assert sp.decode(t[:n].tolist()) == "make the cat larger please"
+    long = tok(" ".join(["cat dog"] * 100))
+    assert long.shape == (64,) and int(long[63]) == 1 and 1 not in long[:63].tolist()      # 63 pieces + EOS: the pooled position is EOS
+    assert tokenizer.canonicalize_text("  A.b,C!!  d\te ") == "abc d e"
+    empty = tok("?!")
+    assert int(empty[0]) == 1 and bool((empty == 1).all())

@@ -997,11 +997,11 @@ def test_my_test_driver_end_to_end_real_model(tmp_path):
     sm_ = torch.stack([prep(root / "dsA" / "mask" / "sup" / f"sm{i}.png", 384, False) for i in range(3)])
     txt = torch.stack([tok(r["Text"]) for r in rows])
 
-    def run(mp, out):
+    def run(mp, out, accelerate=False):
         c = dict(cfg, mixed_precision=mp, vaild_model_save_path=str(tmp_path / out))
-        with open(tmp_path / f"cfg_{mp}.yaml", "w") as f:
+        with open(tmp_path / f"cfg_{out}.yaml", "w") as f:
             yaml.safe_dump(c, f)
-        my_test.main(["--config", str(tmp_path / f"cfg_{mp}.yaml"), "--soft", "1", "--metric", "1"])
+        my_test.main(["--config", str(tmp_path / f"cfg_{out}.yaml"), "--soft", "1", "--metric", "1"] + (["--accelerate", "1"] if accelerate else []))
 
     def pngs(out, i, d):
         return (np.array(Image.open(tmp_path / out / f"hard_pred_{d}" / f"{100 + i}_qm{i}.png")),
@@ -1018,8 +1018,8 @@ def test_my_test_driver_end_to_end_real_model(tmp_path):
                                     support_mask_inputs=sm_[j:j + 2].to(DEV), multimask_output=False)[0] for j in (0, 2)]).float().cpu()
 
     ref_masks, _, _ = omodel.forward(sd, "sam_base", "ViT-B-16-SigLIP-384", "MaskAdapterPooling", q, s_, txt, sm_, False)
-    for mp, out in (("no", "out32"), ("bf16", "out16")):
-        run(mp, out)
+    for mp, out in (("no", "out32"), ("bf16", "out16"), ("bf16", "out16acc")):
+        run(mp, out, accelerate=out.endswith("acc"))                 # third run: Accelerator(bf16) -> prepare(model) -> accelerator.autocast()
         logits = direct(mp == "bf16")
         assert not (tmp_path / out / "hard_pred_Test_1" / "999_qm0.png").exists()
         for i, d in ((0, "Test_1"), (1, "Test_1"), (2, "Test_2")):
@@ -1033,6 +1033,9 @@ def test_my_test_driver_end_to_end_real_model(tmp_path):
             dsoft = np.abs(soft - (rp[0, 0] * 255).to(torch.uint8).numpy().astype(np.int32))
             _note(name=f"my_test_driver_{mp}_sample{i}_vs_direct_call", hard_pixel_agreement=agree, soft_max_grey_diff=int(dsoft.max()))
             assert agree >= 0.9995 and dsoft.max() <= 1, (mp, i, agree, dsoft.max())
+            if out == "out16acc":                                     # the accelerate path writes the SAME files as the plain bf16 run, bit for bit
+                h2, s2 = pngs("out16", i, d)
+                assert np.array_equal(hard, h2) and np.array_equal(soft, s2), (i, d)
             if mp == "no":
                 # (b) exact fp32 mode against the fp32 CPU oracle run on the same files. Budget: with these random weights the mask
                 # decoder is ill-conditioned (test_fp32_mode_per_stage_vs_fp64_oracle measures it on these very inputs: a logit
@@ -1048,6 +1051,36 @@ def test_my_test_driver_end_to_end_real_model(tmp_path):
                 assert agree >= 0.995 and dsoft.mean() <= 1.0, (i, agree, dsoft.mean())
     got = list(_csv.DictReader(open(tmp_path / "out32" / "per_sample_metrics_Test_1.csv")))
     assert [r["Id"] for r in got] == ["100", "101"] and got[0]["Text"].startswith("make the cat")
+
+
+def test_accelerator_prepare_and_autocast_equal_the_direct_bf16_call():
+    """the module must survive accelerator.prepare() (my_test.py:108) and run under accelerator.autocast()
+    (utils/vailder.py:416; config/vaild_config/vaild_a.yaml:4 mixed_precision bf16). The prepared model under the accelerator's
+    autocast must give bit for bit what the direct call under torch.autocast(bf16) gives; state_dict keys survive prepare()."""
+    from accelerate import Accelerator
+    from cor_amd import config
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=2, t_depth=2, vocab=512)
+    model = _build(2, (1,), gcfg, "MaskAdapterPooling")
+    sd = ocfg.random_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 91)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    inp = make_inputs(92, q=(2, 3, 1024, 1024), s=(2, 3, 384, 384), text=("tokens", 2, 64, 512), mask=("mask", 2, 384))
+    kw = dict(query_image_inputs=inp["q"].to(DEV), support_image_inputs=inp["s"].to(DEV), change_text_inputs=inp["text"].to(DEV),
+              support_mask_inputs=inp["mask"].to(DEV), multimask_output=False)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        want = model(**kw)
+    acc = Accelerator(mixed_precision="bf16")
+    prepared = acc.prepare(model)
+    assert set(acc.unwrap_model(prepared).state_dict().keys()) == set(sd.keys())
+    prepared.eval()
+    with torch.no_grad(), acc.autocast():
+        got = prepared(**kw)
+    for a, b, name in zip(got, want, ("masks", "emb", "feat")):
+        assert a.dtype == torch.float32 and torch.equal(a, b), name
+    with torch.no_grad():                                          # outside autocast the prepared model runs its own compute_dtype (fp32 exact)
+        exact = prepared(**kw)
+    direct = model(**kw)
+    assert all(torch.equal(a.float(), b.float()) for a, b in zip(exact, direct))
 
 
 def _driver_like_inputs(n=2):
