@@ -1349,7 +1349,8 @@ def test_preprocess_golden_pillow_and_transforms():
 # through size-independent properties
 # ======================================================================================================
 @pytest.mark.parametrize("sam_name,siglip_name,B,mode", [("sam_base", "ViT-B-16-SigLIP-384", 32, "bf16"), ("sam_base", "ViT-B-16-SigLIP-384", 8, "f32"),
-                                                         ("sam_large", "ViT-L-16-SigLIP-384", 64, "bf16")])      # configs[1] (x2 modes), configs[3]
+                                                         ("sam_large", "ViT-L-16-SigLIP-384", 64, "bf16"),      # configs[1] (x2 modes), configs[3]
+                                                         ("sam_huge", "ViT-SO400M-14-SigLIP-384", 16, "bf16")])  # largest SAM + the factory's DEFAULT tower (lib/build_model.py:14-20,43-47): head_dim 80 / 72 attention, K = 588 / 4304 GEMMs, 729 tokens
 def test_full_size_batch_invariance_and_retrieval(sam_name, siglip_name, B, mode):
     """The oracle cannot run 32 full-size triplets in seconds, so the full configuration is checked through properties:
     (1) batch invariance: every sample of a batch-32 forward (persistent 256x256 GEMM kernel, pipelined attention) equals, bit
