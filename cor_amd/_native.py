@@ -67,6 +67,15 @@ class NativeError(RuntimeError):
     pass
 
 
+def use_probe_library():
+    """Development tools only (tools/attn_stamps.py, tools/gemm_ksweep.py): bind the COR_PROBES build (make -C cor_amd/csrc probes ->
+    tools/probes/libcor_probes.so: timing probes compiled in) instead of the product library. Must be called before load()."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise RuntimeError("use_probe_library() must be called before the library is first loaded")
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "probes", "libcor_probes.so")
+
+
 def load():
     """Load (once) and return the ctypes library; raise loudly when it has not been built."""
     global _lib

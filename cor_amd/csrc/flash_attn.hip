@@ -478,18 +478,13 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 //     had one iteration, about its own global-load latency); one counted wait and one barrier per iteration.
 // LDS = 48 KiB rings + 32 KiB row-bias tables = 80 KiB: two blocks per CU. Tile -1 is a zero V tile with P = 0; the last
 // iteration's S(nt) comes from a stale K tile and is dropped.
-// FOLD (q_prescale = scale * log2 e folded into q by the caller, a.scale_log2 == 1): the softmax VALU, not the matrix pipe,
-// bounds this kernel (132 VALU + 32 quarter-rate exp2 against 20 MFMAs per tile and wave; matrix pipe 43 % busy), so the bias
-// and the running reference move ONTO the matrix pipe as extra k-steps of the score product:
-//     S(t)^T += I_perm . colbias^T            (4 MFMAs: the column bias as bf16 hi + lo halves against a permuted identity whose
-//                                              k-slot order is the accumulator's own row order: no exchange, 2^-17 relative)
-//     S(t)^T += ones . (rowbias(t) - m)^T     (1 MFMA per key block: three k-slots hold the bf16 hi / mid / lo parts)
-// and the MFMA result is already  x - m  in the log2 domain: a score costs  max + exp2 + cvt_pk/2  instead of
-// fma + max + sub + exp2 + cvt_pk/2  (-64 VALU, +10 MFMAs per tile). (Round 2 first tried the same fold through the
-// accumulator's start values - one add per score instead of two ops - which measured SLOWER: the adds sat on the MFMA's
-// critical path; an MFMA that starts from the inline constant 0 does not wait for VALU results.)
-template <typename TO, int FOLD, int NW = 4, bool STAMP = false, bool VS = true>     // VS: row sums of P on the VALU (32 adds) instead of 4 MFMAs; FOLD 0: fma form; 1: row bias - reference folded; 2: column bias folded too
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(const FlashArgs a) {   // STAMP: timing probe (tools/attn_stamps.py): cycle sums instead of outputs   // NW waves x 32 queries per block
+// Variants tried and measured slower (round 2, profiles/r02_attention_fold_ablation.jsonl, r02_attention_pingpong_stamps.jsonl; their
+// code is in the history up to commit 5d3e0f7): bias / running reference as extra k-steps of the score MFMA (+1 % / +12 %), 8-wave
+// blocks (+5 %), an explicit ping-pong form with alternating matrix / softmax segments (+5 %), row sums of P by a ones-row MFMA (+4 %).
+// STAMP (COR_PROBES builds only, tools/attn_stamps.py): per-section cycle sums are written INSTEAD of the outputs.
+template <typename TO, bool STAMP = false>
+__global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {   // 4 waves x 32 queries per block
+  constexpr int NW = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_BYTES = 3 * TILE_B, V_BYTES = 3 * TILE_B;         // rings of three 8-KiB tiles each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -516,9 +511,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
   float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUX_PER_WAVE);
   float wreg[2][16];
   {
-    // scratch of the table products: aliases the K/V rings (48 KiB: six waves; barrier before staging), waves 6-7 of the
-    // 8-wave form use 16 KiB behind the row-bias tables
-    float* scr = (float*)(smem + (NW == 8 && wave >= 6 ? K_BYTES + V_BYTES + NW * AUX_PER_WAVE + (wave - 6) * AUX_PER_WAVE : wave * AUX_PER_WAVE));
+    // scratch of the table products: aliases the K/V rings (barrier before staging)
+    float* scr = (float*)(smem + wave * AUX_PER_WAVE);
 #pragma unroll 1
     for (int tbl = 0; tbl < 2; ++tbl) {
       const float* table = tbl == 0 ? a.rel_h : a.rel_w;
@@ -557,53 +551,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
       }
     }
   }
-  // FOLD operands. Column bias: B operand of k-step cc of key block kb = the lane's own wreg[kb][8 cc .. 8 cc + 7] (k-slot
-  // 8 h + i <-> accumulator row acc_row(8 cc + i, h)), split into a truncated bf16 hi half and the (exactly representable
-  // remainder's) bf16 lo half; the A operand is the matching permuted identity. Row bias: A = ones in k-slots 0..2.
-  uint4 twh[2][2], twl[2][2], idA[2], oneA;
-  if (FOLD == 2) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        unsigned hi[8]; float lo[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          hi[i] = __float_as_uint(wreg[kb][8 * cc + i]) & 0xffff0000u;
-          lo[i] = wreg[kb][8 * cc + i] - __uint_as_float(hi[i]);
-        }
-        twh[kb][cc] = make_uint4((hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3], (hi[4] >> 16) | hi[5], (hi[6] >> 16) | hi[7]);
-        twl[kb][cc] = pack8(lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]);
-      }
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      unsigned w[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned e0 = r == acc_row(8 * cc + 2 * j, h) ? 0x3F80u : 0u, e1 = r == acc_row(8 * cc + 2 * j + 1, h) ? 0x3F800000u : 0u;
-        w[j] = e0 | e1;
-      }
-      idA[cc] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-  }
-  if (FOLD) oneA = h == 0 ? make_uint4(0x3F803F80u, 0x00003F80u, 0, 0) : make_uint4(0, 0, 0, 0);
-  // (row bias - reference) as three bf16 parts in k-slots 0..2 (24 mantissa bits: the sum is exact in the fp32 accumulator)
-  auto th_operand = [&](float c) -> uint4 {
-    const unsigned c0 = __float_as_uint(c) & 0xffff0000u;
-    const float r1 = c - __uint_as_float(c0);
-    const unsigned c1 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(c1);
-    return make_uint4((c0 >> 16) | c1, __float_as_uint(r2) >> 16, 0, 0);
-  };
-  // the bias k-steps of one key block: 4 column-bias MFMAs + 1 row-bias MFMA
-  auto fold_bias = [&](f32x16 acc, int kb, uint4 thB) -> f32x16 {
-#pragma unroll
-    for (int cc = 0; cc < (FOLD == 2 ? 2 : 0); ++cc) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, idA[cc]), __builtin_bit_cast(bf16x8, twh[kb][cc]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, idA[cc]), __builtin_bit_cast(bf16x8, twl[kb][cc]), acc, 0, 0, 0);
-    }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, oneA), __builtin_bit_cast(bf16x8, thB), acc, 0, 0, 0);
-  };
   __syncthreads();
 
   // ---- staging: LDS-DMA (global_load_lds_dwordx4), no registers. A tile is 64 rows x 128 B = 512 chunks of 16 B; thread tid
@@ -621,23 +568,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
   // with bit 1 set store their two 64-byte halves exchanged (source chunk ^ 4), the reader picks window db ^ bit 1 of its row.
   const int vswz = (sch ^ (((srow >> 1) & 1) << 2)) * 8;
   const bf16_t* kv0 = kvbase + (long)srow * a.d3;           // row srow of tile 0; + 32*d3 for the second chunk
-  // (NW = 8: 512 threads, one chunk each - half the LDS-DMA instructions per wave and tile, and K/V cross L2 -> LDS once per
-  // 256 queries instead of once per 128)
   auto issue_k = [&](int t, int slot) {
     const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + a.H * 64 + kswz;
     const unsigned d = lds0 + slot * TILE_B + wofs;
     glds16(p0, d);
-    if (NW == 4) glds16(p0 + 32L * a.d3, d + 4096);
+    glds16(p0 + 32L * a.d3, d + 4096);
   };
   auto issue_v = [&](int t, int slot) {
     const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + vswz;
     const unsigned d = lds0 + K_BYTES + slot * TILE_B + wofs;
     glds16(p0, d);
-    if (NW == 4) glds16(p0 + 32L * a.d3, d + 4096);
+    glds16(p0 + 32L * a.d3, d + 4096);
   };
   issue_k(0, 0); issue_k(1, 1); issue_k(2, 2); issue_v(0, 0);
   *(uint4*)(Vring + 2 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 2)
-  if (NW == 4) *(uint4*)(Vring + 2 * TILE_B + 4096 + tid * 16) = make_uint4(0, 0, 0, 0);
+  *(uint4*)(Vring + 2 * TILE_B + 4096 + tid * 16) = make_uint4(0, 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -656,8 +601,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) lsum[e] = 0.f;
-  float m = FOLD ? 0.f : -INFINITY;                    // FOLD: the reference is 0 until tile 0 has been seen
-  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
+  float m = -INFINITY;
   uint4 pf[2][2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) { pf[kb][0] = make_uint4(0, 0, 0, 0); pf[kb][1] = make_uint4(0, 0, 0, 0); }
@@ -667,31 +611,17 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
   for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-    if (FOLD) s[kb] = fold_bias(s[kb], kb, th_operand(aux[r]));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint4 kf = *(const uint4*)(Kring + kb * 32 * 128 + kch[c]);
       s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
     }
   }
-  if (FOLD) {                                           // the reference starts at tile 0's maximum (O = l = 0: nothing to rescale)
-    float m0 = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) m0 = fmaxf(m0, FOLD == 1 ? s[kb][e] + wreg[kb][e] : s[kb][e]);
-    m = fmaxf(m0, other_half(m0));
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[kb][e] -= m;
-  }
   __syncthreads();                                      // every wave is done with K tile 0 before iteration 0 refills its slot
 
   int c3 = 0;                                           // t % 3
   unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};      // STAMP: cycles in [DMA issue | phase A | reference update | phase B | vmcnt wait | barrier]
-  // one key tile; S(t) arrives in `s`, S(t+1) leaves in `sn`. FOLD consumes the raw MFMA result in the NEXT iteration, so the
-  // loop below runs two tiles per trip with the two register sets swapping roles (a single-tile loop copied 32 registers per tile)
+  // one key tile; S(t) arrives in `s`, S(t+1) leaves in `sn`
   auto tile_step = [&](const int t, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
     const int c3p1 = c3 == 2 ? 0 : c3 + 1, c3p2 = c3 == 0 ? 2 : c3 - 1;      // (t+1) % 3, (t+2) % 3 = (t-1) % 3
     unsigned long long ts[8];
@@ -704,7 +634,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     stamp(1);
     const char* Vs = Vring + c3p2 * TILE_B;             // V(t-1)
     const char* Ks = Kring + c3p1 * TILE_B;             // K(t+1)
-    const float rh = FOLD ? aux[min(t + 1, nt - 1) * 32 + r] : aux[t * 32 + r];   // FOLD: row bias of the NEXT tile (folded into S(t+1))
+    const float rh = aux[t * 32 + r];
     // ---- phase A: PV(t-1) and row-sum MFMAs beside (scale + bias +) max of S(t)
     uint4 vf[8];
 #pragma unroll
@@ -721,41 +651,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     for (int i = 0; i < 8; ++i) {
       const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-      if (!VS && db == 1) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
     }
     float mloc = -INFINITY;
-    int imax = 0;
-    if (FOLD == 1) {
-      // S(t) is x - m short of the column bias: one add per score, then only max(0, tile maximum) is needed
-      float pmax = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const float x0 = s[kb][e] + wreg[kb][e], x1 = s[kb][e + 1] + wreg[kb][e + 1];
-          s[kb][e] = x0; s[kb][e + 1] = x1;
-          pmax = fmaxf(pmax, fmaxf(x0, x1));
-        }
-      imax = __float_as_int(pmax);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      }
-    } else if (FOLD == 2) {
-      // S(t) is already x - m: only max(0, tile maximum) is left to the VALU, and for that the INTEGER maximum of the float
-      // bit patterns is exact (any positive float beats every negative one and positives order like their bits; a float max
-      // of raw MFMA results would cost a canonicalising v_max per operand)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) imax = max(imax, max(__float_as_int(s[kb][e]), __float_as_int(s[kb][e + 1])));
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 2 VALU
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      }
-    } else {
+    {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -773,31 +671,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     __builtin_amdgcn_sched_barrier(0);
     stamp(2);
     float msub = 0.f;
-    if (FOLD) {
-      // reference update only when a tile maximum exceeds it by 2^8 (lazy rescale); S(t+1) is issued below, after the update,
-      // so its row-bias operand carries the new reference
-      if (__builtin_amdgcn_ballot_w64(imax > 0x41000000) != 0) {               // some x - m > 8.0f
-        mloc = __int_as_float(imax);
-        const float d = fmaxf(mloc, other_half(mloc)); // >= 0
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        m += d;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[kb][e] -= d;
-        lsum[0] *= alpha; if (VS) { lsum[1] *= alpha; lsum[2] *= alpha; }
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-      }
-    } else {
+    {
       mloc = fmaxf(mloc, other_half(mloc)) + rh;        // true tile max (x + rh)
       if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {     // lazy rescale (see the header)
         const float mnew = fmaxf(m, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         m = mnew;
-        lsum[0] *= alpha; if (VS) { lsum[1] *= alpha; lsum[2] *= alpha; }
+        lsum[0] *= alpha; lsum[1] *= alpha; lsum[2] *= alpha;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -814,38 +694,33 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
-    uint4 thB = make_uint4(0, 0, 0, 0);
-    if (FOLD) thB = th_operand(rh - m);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), sn[kb], 0, 0, 0);
-      if (FOLD) sn[kb] = fold_bias(sn[kb], kb, thB);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 p;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(FOLD ? s[kb][e] : s[kb][e] - msub);
-      if (VS) {                                         // this lane's 16 keys of the block (the other lane half holds the other 16)
-        lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
-        lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
-      }
+      for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub);
+      // row sums: this lane's 16 keys of the block (the other lane half holds the other 16)
+      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
+      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
     }
 #pragma unroll
-    for (int i = 0; i < (FOLD == 2 ? 18 : FOLD == 1 ? 10 : 8); ++i) {         // 1 MFMA : 11 (FOLD 1: 6, 2: 3) VALU
+    for (int i = 0; i < 8; ++i) {         // 1 MFMA : 11 VALU
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, FOLD == 2 ? 3 : FOLD == 1 ? 6 : 11, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     c3 = c3p1;
     stamp(4);
-    if (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 (NW = 8: 2) stay in flight
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 stay in flight
     stamp(5);
     __syncthreads();
     stamp(6);
@@ -855,13 +730,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     }
   };
   f32x16 s2[2];
-  if (FOLD == 2) {
-#pragma unroll 1
-    for (int t = 0; t < nt; t += 2) {                   // nt = 64 (the host checks grid == 64)
-      tile_step(t, s, s2);
-      tile_step(t + 1, s2, s);
-    }
-  } else {
+  {
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) {
       tile_step(t, s, s2);
@@ -886,10 +755,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
           const uint4 vfr = make_uint4(u0.x, u0.y, u1.x, u1.y);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
         }
-        if (!VS) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[kb][ks]), lsum, 0, 0, 0);
       }
   }
-  if (VS) { const float l = lsum[1] + lsum[2]; lsum[0] = l + other_half(l); }
+  { const float l = lsum[1] + lsum[2]; lsum[0] = l + other_half(l); }
 
   if (STAMP) {                                          // probe build: no outputs, six cycle sums per wave at the start of `o`
     if (lane == 0) {
@@ -900,251 +768,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) flash_global_pipe(co
     return;
   }
   const float inv = 1.0f / lsum[0];                     // full row sum (the MFMA already summed both lane halves)
-  auto off = [&](int j) -> long {
-    const int tj = qt_ * (NW * 32) + wave * 32 + j;
-    return tj < a.Tq ? ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64 : -1L;
-  };
-  store_o_rows<TO, 64>(o, inv, (char*)aux, (TO*)a.o, lane, off);   // the wave's row-bias table is dead: 8 KiB of private staging
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Global SAM attention, PING-PONG form (variant 5): the arithmetic of flash_global_pipe in 8-wave blocks (256 queries) whose two
-// wave groups (waves 0-3 / 4-7: waves w and w + 4 share a SIMD) run ONE barrier interval apart, so that on every SIMD one
-// wave is in its matrix segment while its partner is in its softmax segment (the stamps of the default kernel show the matrix
-// and vector work of two co-resident, unsynchronised waves barely overlapping). A wave's iteration t is
-//     M(t):  O^T += V(t-1)^T . P(t-1)^T (+ row sums)  and  S(t)^T = K(t) . Q^T          (20 MFMAs, fragments read at the top)
-//     V(t):  scale + bias + max of S(t), lazy reference update, exp2 and bf16 packing of P(t)            (VALU only)
-// with a block barrier after each segment; group 1 executes one extra barrier before its loop, group 0 one after. (No score
-// tile is computed ahead: inside one wave M and V alternate strictly, the overlap comes from the partner - 32 registers less.)
-// K / V rings of FOUR tiles: every wave copies its 8 rows of K(t+3) and V(t+2) at the top of M(t) (both slots were last read
-// in M(t-1), which the lagging group finished before the barrier group 0 has just passed) and waits with vmcnt(2) at the
-// end of V(t), i.e. for the copies of iteration t-1; those are published by the barrier the lagging group passes at the end
-// of its V(t) and first read in M(t+2). LDS = 64 KiB rings + 64 KiB row-bias tables: one block per CU, two waves per SIMD.
-template <typename TO, bool STAMP = false, int ABL = 0>   // ABL: timing ablations of the probe build only (1 no exp2, 2 no max chain, 3 no fma, 4 no frag reads)
-__global__ void __launch_bounds__(512, 1) flash_global_pp(const FlashArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = 8, K_BYTES = 4 * TILE_B, V_BYTES = 4 * TILE_B;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
-  const int r = lane & 31, h = lane >> 5;
-  const int wi0_ = xcd_remap(blockIdx.x, gridDim.x);
-  const int wi_ = a.rev ? (int)gridDim.x - 1 - wi0_ : wi0_;
-  const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
-  const int head = hb_ % a.H, b = hb_ / a.H;
-  const int S = a.S;                                   // 64
-  const int g2 = a.grid * a.grid;
-  const bf16_t* kvbase = a.q + (long)b * g2 * a.d3 + head * 64;
-
-  int tq = qt_ * (NW * 32) + wave * 32 + r;
-  tq = min(tq, a.Tq - 1);
-  const int qh = tq / S, qw = tq - qh * S;
-  const long orow = (long)b * g2 + tq;
-  const bf16_t* qp = a.q + orow * a.d3 + head * 64;
-  uint4 qf[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) qf[c] = *(const uint4*)(qp + 16 * c + 8 * h);
-
-  // ---- relative-position tables (log2 domain): row part -> aux[kh][q] (LDS), column part -> 32 registers
-  float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUX_PER_WAVE);
-  float wreg[2][16];
-  {
-    float* scr = (float*)(smem + wave * AUX_PER_WAVE);            // aliases the K/V rings (64 KiB): barrier before staging
-#pragma unroll 1
-    for (int tbl = 0; tbl < 2; ++tbl) {
-      const float* table = tbl == 0 ? a.rel_h : a.rel_w;
-#pragma unroll 1
-      for (int half = 0; half < 2; ++half) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
-          const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
-                                                              __builtin_bit_cast(bf16x8, qf[c]), acc[jb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
-        if (tbl == 0) {
-#pragma unroll 4
-          for (int i = 0; i < 32; ++i) {
-            const int kh = 32 * h + i, j = qh + (S - 1) - kh;
-            if ((j >> 6) == half) aux[kh * 32 + r] = scr[(j & 63) * 32 + r];
-          }
-        } else {
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int kw = kb * 32 + acc_row(e, h), j = qw + (S - 1) - kw;
-              if ((j >> 6) == half) wreg[kb][e] = scr[(j & 63) * 32 + r];
-            }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- staging: LDS-DMA, one 16-B chunk per thread and tile (512 chunks = 64 rows x 128 B); K swizzled on the source side
-  char* Kring = smem; char* Vring = smem + K_BYTES;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
-  const unsigned wofs = wave * 1024u;
-  const int nt = a.Tk / KT;
-  const int srow = tid >> 3, sch = tid & 7;
-  const int kswz = (sch ^ ((srow >> 1) & 7)) * 8;
-  const bf16_t* kv0 = kvbase + (long)srow * a.d3;
-  auto issue_k = [&](int t) {
-    glds16(kv0 + (long)min(t, nt - 1) * KT * a.d3 + a.H * 64 + kswz, lds0 + (t & 3) * TILE_B + wofs);
-  };
-  auto issue_v = [&](int t) {
-    glds16(kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + sch * 8, lds0 + K_BYTES + (t & 3) * TILE_B + wofs);
-  };
-  issue_k(0); issue_k(1); issue_k(2); issue_v(0); issue_v(1);
-  *(uint4*)(Vring + 3 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 3)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- fragment read maps
-  const int sw = (lane >> 1) & 7;
-  int kch[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) kch[c] = r * 128 + (((2 * c + h) ^ sw) << 4);
-  const int v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-
-  f32x16 o[2], s[2], lsum;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) lsum[e] = 0.f;
-  float m = -INFINITY;
-  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
-  uint4 pf[2][2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) { pf[kb][0] = make_uint4(0, 0, 0, 0); pf[kb][1] = make_uint4(0, 0, 0, 0); }
-
-  // fragments of the NEXT matrix segment are read at the top of the softmax segment before it (their LDS latency hides under
-  // the VALU work): vf = V(t-1), kf = K(t) for M(t)
-  uint4 vf[8], kf[8];
-  auto read_frags = [&](int tv, int tk) {              // V(tv) and K(tk) (slot = tile & 3)
-    const char* Vs = Vring + (tv & 3) * TILE_B;
-    const char* Ks = Kring + (tk & 3) * TILE_B;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
-      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + db * 64 + v_tr;
-      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
-      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
-      const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
-      vf[i] = make_uint4(u0.x, u0.y, u1.x, u1.y);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kf[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
-  };
-  read_frags(3, 0);                                     // V(-1) (the zero tile in slot 3), K(0)
-  if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one interval behind group 0
-
-  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};      // STAMP: [copy issue | M | barrier | V | vmcnt wait | barrier]
-#pragma unroll 1
-  for (int t = 0; t < nt; ++t) {
-    unsigned long long ts[8];
-    auto stamp = [&](int i) { if (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } };
-    // ================= M(t): copies of K(t+3), V(t+2); QK(t); PV(t-1) + row sums
-    stamp(0);
-    issue_k(t + 3);
-    issue_v(t + 2);
-    const float rh = aux[t * 32 + r];                   // (wave-private table: read here, ahead of the 24 fragment reads of V(t))
-    stamp(1);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), s[kb], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
-      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(2);
-    __builtin_amdgcn_s_barrier();
-    stamp(3);
-    // ================= V(t): fragments for M(t+1) = V(t), K(t+1) (published by the barrier just passed); softmax of S(t) -> P(t)
-    if (ABL != 4) read_frags(t, t + 1);
-    float mloc = -INFINITY, ml1 = -INFINITY, ml2 = -INFINITY, ml3 = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const float x0 = ABL == 3 ? s[kb][e] : fmaf(s[kb][e], a.scale_log2, wreg[kb][e]), x1 = ABL == 3 ? s[kb][e + 1] : fmaf(s[kb][e + 1], a.scale_log2, wreg[kb][e + 1]);
-        s[kb][e] = x0; s[kb][e + 1] = x1;
-        if (ABL != 2) {                                 // four independent maximum chains
-          float& mm = ((e >> 1) & 3) == 0 ? mloc : ((e >> 1) & 3) == 1 ? ml1 : ((e >> 1) & 3) == 2 ? ml2 : ml3;
-          mm = fmaxf(mm, fmaxf(x0, x1));
-        }
-      }
-    if (ABL == 2) mloc = s[0][0];
-    else mloc = fmaxf(fmaxf(mloc, ml1), fmaxf(ml2, ml3));
-    mloc = fmaxf(mloc, other_half(mloc)) + rh;          // true tile max (x + rh)
-    if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {     // lazy rescale
-      const float mnew = fmaxf(m, mloc);
-      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-      m = mnew;
-      lsum[1] *= alpha; lsum[2] *= alpha;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-    }
-    const float msub = m - rh;                          // p = 2^(x + rh - m)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 p;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) p[e] = ABL == 1 ? s[kb][e] - msub : __builtin_amdgcn_exp2f(s[kb][e] - msub);
-      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
-      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
-      pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
-      pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
-    }
-    stamp(4);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // the copies of iteration t-1 (K(t+2), V(t+1)) have landed; this iteration's 2 stay in flight
-    stamp(5);
-    __builtin_amdgcn_s_barrier();
-    stamp(6);
-    if (STAMP) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) tsum[i] += ts[i + 1] - ts[i];
-    }
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();           // balance group 1's extra barrier
-  // PV(nt-1) and its row sums: vf already holds V(nt-1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail copies must not outlive the block
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
-    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-  }
-  { const float l = lsum[1] + lsum[2]; lsum[0] = l + other_half(l); }
-  if (STAMP) {
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) ((unsigned long long*)a.o)[((long)blockIdx.x * NW + wave) * 8 + i] = tsum[i];
-      ((unsigned long long*)a.o)[((long)blockIdx.x * NW + wave) * 8 + 6] = (unsigned long long)(o[0][0] + lsum[0] != 12345.f);
-    }
-    return;
-  }
-  const float inv = 1.0f / lsum[0];
   auto off = [&](int j) -> long {
     const int tj = qt_ * (NW * 32) + wave * 32 + j;
     return tj < a.Tq ? ((long)b * g2 + tj) * (long)(a.H * 64) + head * 64 : -1L;
@@ -1392,43 +1015,16 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO, int FOLD, int NW = 4, bool STAMP = false, bool VS = true>
-int launch_global_pipe_(const FlashArgs& a, int nb, hipStream_t s) {
-  const size_t lds = 6 * TILE_B + NW * AUX_PER_WAVE + (NW == 8 ? 2 * AUX_PER_WAVE : 0);    // 80 KiB: two blocks per CU; NW = 8: 128 KiB, one
+template <typename TO, bool STAMP = false>
+int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
+  const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO, FOLD, NW, STAMP, VS>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, STAMP>, (int)lds, once);
   FlashArgs b = a;
-  b.nqt = cdiv(a.Tq, NW * 32);
-  hipLaunchKernelGGL((flash_global_pipe<TO, FOLD, NW, STAMP, VS>), dim3(b.nqt * a.H * nb), dim3(NW * 64), lds, s, b);
+  b.nqt = cdiv(a.Tq, 128);
+  hipLaunchKernelGGL((flash_global_pipe<TO, STAMP>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
-}
-// FOLD (bias and reference as extra k-steps of the score MFMA, see the kernel header) needs q pre-scaled by scale * log2 e
-// (a.scale_log2 == 1); raw-q callers get the fma form.
-template <typename TO, bool STAMP = false, int ABL = 0>
-int launch_global_pp(const FlashArgs& a, int nb, hipStream_t s) {
-  const size_t lds = 8 * TILE_B + 8 * AUX_PER_WAVE;    // 128 KiB: one 8-wave block per CU
-  static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pp<TO, STAMP, ABL>, (int)lds, once);
-  FlashArgs b = a;
-  b.nqt = cdiv(a.Tq, 256);
-  hipLaunchKernelGGL((flash_global_pp<TO, STAMP, ABL>), dim3(b.nqt * a.H * nb), dim3(512), lds, s, b);
-  COR_CHECK_LAUNCH();
-  return 0;
-}
-template <typename TO>
-int launch_global_pipe(const FlashArgs& a, int nb, int fold, hipStream_t s) {
-  if (fold == 5) return launch_global_pp<TO>(a, nb, s);
-  if (fold == 6) return launch_global_pipe_<TO, 0, 4, false, false>(a, nb, s);   // row sums of P by a ones-row MFMA (the round-1 form; variant 6)
-  if (fold == 10) return launch_global_pp<TO, true>(a, nb, s);    // timing probe of the ping-pong form (variant 10)
-  if (fold >= 11 && fold <= 14) {                                    // probe-only ablations of the softmax segment (tools/attn_stamps.py B pp N)
-    return fold == 11 ? launch_global_pp<TO, true, 1>(a, nb, s) : fold == 12 ? launch_global_pp<TO, true, 2>(a, nb, s)
-         : fold == 13 ? launch_global_pp<TO, true, 3>(a, nb, s) : launch_global_pp<TO, true, 4>(a, nb, s);
-  }
-  if (a.scale_log2 != 1.0f && fold < 5) fold = 0;
-  if (fold == 8) return launch_global_pipe_<TO, 0, 8>(a, nb, s);     // 8-wave blocks (variant 4)
-  if (fold == 9) return launch_global_pipe_<TO, 0, 4, true>(a, nb, s);   // timing probe (variant 9): cycle sums instead of outputs
-  return fold == 2 ? launch_global_pipe_<TO, 2>(a, nb, s) : fold == 1 ? launch_global_pipe_<TO, 1>(a, nb, s) : launch_global_pipe_<TO, 0>(a, nb, s);
 }
 
 template <int MODE, typename TO, int HD = 64>
@@ -1453,16 +1049,10 @@ int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
 }  // namespace
 
 // `variant` (per call): 0 (default) = flash_global_pipe (global; software-pipelined over key tiles) / win_attn (windowed; one
-// 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>, the round-1 chain forms of the same arithmetic (kept as
-// the in-process A/B and parity partners: tests/test_gpu_parity.py, tools/attn_bench.py); 2 / 3 = global attention with the
-// column + row bias and the running reference (2) or the row bias and reference only (3) as extra k-steps of the score MFMA
-// (needs q_prescale = scale * log2 e). Measured at B = 32 (profiles/r02_attention_fold_ablation.jsonl): variant 0 2.29-2.39 ms,
-// variant 3 2.41-2.42 ms (-33 VALU, +2 MFMAs per tile: +1 %), variant 2 2.57-2.68 ms (-64 VALU, +10 MFMAs: +12 %), variant 1
-// 2.40-2.51 ms: the kernel's time does not follow its VALU count, so the default stays the fma form. 4 = the default arithmetic in
-// 8-wave blocks (256 queries per block: K/V cross L2 -> LDS once per 256 queries, half the LDS-DMA instructions per wave):
-// bit-identical, 2.44-2.46 vs 2.31-2.32 ms (the per-tile barrier then spans 8 waves). 5 = ping-pong form (flash_global_pp),
-// 6 = row sums by a ones-row MFMA (round-1 form: 2.29-2.30 vs 2.21 ms). 9 = timing probe of the default kernel:
-// per-wave s_memtime sums per loop section are written INSTEAD of the outputs (tools/attn_stamps.py).
+// 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>, the round-1 chain forms of the same arithmetic, kept as the
+// in-process A/B and parity partners (tests/test_gpu_parity.py, tools/attn_bench.py). Anything else is COR_EINVAL in the
+// production library; a COR_PROBES build (make probes -> tools/probes/libcor_probes.so) adds 9 = the timing probe of the default
+// global kernel (per-wave s_memtime sums per loop section INSTEAD of the outputs: tools/attn_stamps.py).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
                          void* out, long o_sb, long o_st, int out_dtype, int B, int H, int Tq, int Tk, int hd, float scale, hipStream_t s) {
   // 16-B fragment loads: every row start must be 16-B aligned
@@ -1484,6 +1074,11 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   if (hd != 64 && hd != 80) return COR_ENOSUPPORT;     // SAM-B/L: 64, SAM-H: 80
   const int rev = (variant & COR_ORDER_REVERSE) ? 1 : 0;
   variant &= ~COR_ORDER_REVERSE;
+#ifdef COR_PROBES
+  if (variant != 0 && variant != 1 && variant != 9) return COR_EINVAL;
+#else
+  if (variant != 0 && variant != 1) return COR_EINVAL;   // no probe / experimental kernels in the production library
+#endif
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
   a.q = (const bf16_t*)qkv; a.o = out; a.H = H; a.rev = rev;
@@ -1494,10 +1089,15 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
-    if (variant == 0 || variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 6 || variant == 9 || (variant >= 10 && variant <= 14)) {
-      const int fold = variant == 2 ? 2 : variant == 3 ? 1 : variant == 4 ? 8 : variant == 5 ? 5 : variant == 6 ? 6 : variant >= 9 ? variant : 0;
-      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, fold, s);
-      if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, fold, s);
+#ifdef COR_PROBES
+    if (variant == 9) {
+      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t, true>(a, B, s);
+      if (out_dtype == COR_F32) return launch_global_pipe<float, true>(a, B, s);
+    }
+#endif
+    if (variant == 0) {
+      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, s);
+      if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, s);
     }
     if (out_dtype == COR_BF16) return launch<1, bf16_t>(a, B, s);
     if (out_dtype == COR_F32) return launch<1, float>(a, B, s);

@@ -20,6 +20,14 @@
 //   * XCD-aware tile order: blocks that share an XCD walk N-tiles of the same A row-panel (L2 reuse of A).
 #include "common.h"
 
+// Timing-only ablation knobs (no C stores / no epilogue / no MFMA / no LDS-DMA issue, tile-order band height, 16x16x32 MFMAs) exist
+// in COR_PROBES builds only (make probes -> tools/probes/libcor_probes.so, used by tools/gemm_ksweep.py): they destroy results, so
+// the production library compiles them out and cor_gemm answers COR_EINVAL to their selectors.
+#ifdef COR_PROBES
+#define COR_DBG(g_, bit_) ((g_).dbg & (bit_))
+#else
+#define COR_DBG(g_, bit_) 0
+#endif
 #ifndef COR_GEMM_DEFAULT_BIG
 #define COR_GEMM_DEFAULT_BIG 2
 #endif
@@ -125,7 +133,7 @@ __device__ __forceinline__ void epilogue_vec_ct(const f32x16 (&acc)[MI][NJ], flo
         v[q4] *= sv[q4];
         if constexpr (HAS_RES) v[q4] += res[j][q4];
       }
-      if (m < g.M && n < g.N && !(g.dbg & 1)) {
+      if (m < g.M && n < g.N && !COR_DBG(g, 1)) {
         TO* cp = C + (long)m * g.ldc + n;
         if constexpr (VW == 8) {
           if (n + 8 <= g.N) {
@@ -570,7 +578,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) af[i][s4] = *(const uint4*)(asl + i * 32 * 128 + chs[s4]);
       }
-      if (kt > 0 && kt + 1 < nkt && !(g.dbg & 8)) {   // B(1) came with the prologue
+      if (kt > 0 && kt + 1 < nkt && !COR_DBG(g, 8)) {   // B(1) came with the prologue
         const int sb = 6 + 2 * ((kt + 1) & 1);
         issue_b(0, kt + 1, sb); issue_b(1, kt + 1, sb + 1);
       }
@@ -604,7 +612,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) af[i][s4] = *(const uint4*)(asl + (64 + i * 32) * 128 + chs[s4]);
       }
-      if (kt + 2 < nkt && !(g.dbg & 8)) { const int sa = 2 * (a3 == 0 ? 2 : a3 - 1); issue_a(0, kt + 2, sa); issue_a(1, kt + 2, sa + 1); }
+      if (kt + 2 < nkt && !COR_DBG(g, 8)) { const int sa = 2 * (a3 == 0 ? 2 : a3 - 1); issue_a(0, kt + 2, sa); issue_a(1, kt + 2, sa + 1); }
       if (kt == 0 && stores_pending) {               // A(1), B(1) are older than the stores: leave the stores (and A(2)) in flight
         if (nkt > 1) {
           if constexpr (NSTORE == 16) { if (nkt > 2) COR_VMCNT(20); else COR_VMCNT(16); }
@@ -658,7 +666,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #define COR_EPI(A_)                                                                                             \
     if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true>(fill, stg, g, crs, mb, nb, lane);                   \
     else epilogue_buf_ct<TO, MI, NJ, A_, false>(fill, stg, g, crs, mb, nb, lane);
-    if (g.dbg & 2) {                                 // timing ablation: one element per lane instead of the epilogue
+    if (COR_DBG(g, 2)) {                             // timing ablation: one element per lane instead of the epilogue
       float t = 0.f;
       if constexpr (M16) {
 #pragma unroll
@@ -683,7 +691,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #undef COR_EPI
     if (Ln >= total) break;
     L = Ln;
-    stores_pending = !(g.dbg & 2);
+    stores_pending = !COR_DBG(g, 2);
   }
 }
 
@@ -725,8 +733,8 @@ __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, cons
   }
 }
 
-// `cfg` (per call, last argument of cor_gemm): low byte 0 = auto; 1, 2, 3, 4, 9, 13, 14 force a kernel (tools/gemm_bench.py);
-// bits 8.. = timing-only ablation / tile-order knobs of the persistent kernel (tools/gemm_ksweep.py). No process-global state.
+// `cfg` (per call, last argument of cor_gemm): low byte 0 = auto; 1, 2, 3, 4, 9, 13 force a kernel (tools/gemm_bench.py); COR_PROBES
+// builds add 14 (16x16x32 MFMAs) and, in bits 8.., the timing-only ablation / tile-order knobs (tools/gemm_ksweep.py). No process-global state.
 
 template <typename TA, typename TO, int BM, int BN, int WM, int WN, bool GLDS, int NBUF = 2>
 int launch_tile(GemmArgs g, hipStream_t s) {
@@ -782,15 +790,21 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     if (!ok) cfg = k128 ? 2 : 1;
     else if constexpr (sizeof(TA) == 2) {
       g.tm = cdiv(g.M, 256); g.tn = cdiv(g.N, 256);
-      static DevOnce once_a, once_b;
+      static DevOnce once_a;
       const int n_cu = cor_device_cus();
       cor_max_dyn_lds((const void*)gemm_pp<TO, false>, 163840, once_a);
+#ifdef COR_PROBES
+      static DevOnce once_b;
       cor_max_dyn_lds((const void*)gemm_pp<TO, true>, 163840, once_b);
+#endif
       const int total = g.tm * g.tn;
       int blocks = n_cu - (n_cu & 7);
       if (total < blocks) blocks = ((total + 7) / 8) * 8;
+#ifdef COR_PROBES
       if (cfg == 14) hipLaunchKernelGGL((gemm_pp<TO, true>), dim3(blocks), dim3(512), 163840, s, g);
-      else hipLaunchKernelGGL((gemm_pp<TO, false>), dim3(blocks), dim3(512), 163840, s, g);
+      else
+#endif
+      hipLaunchKernelGGL((gemm_pp<TO, false>), dim3(blocks), dim3(512), 163840, s, g);
       COR_CHECK_LAUNCH();
       return 0;
     }
@@ -811,7 +825,15 @@ extern "C" int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab
                         int M, int N, int K, const float* bias, int act, const float* col_scale,
                         const float* residual, long ldr, int res_row_mod, int cfg, void* stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldc < N) return COR_EINVAL;
-  if (cfg < 0 || (cfg & 0xff) > 14) return COR_EINVAL;
+  {
+    const int sel = cfg & 0xff;
+#ifdef COR_PROBES
+    if (cfg < 0 || sel > 14) return COR_EINVAL;
+#else
+    // production: automatic or one of the shipped kernels, optionally | COR_ORDER_REVERSE; no ablation bits, no 16x16 probe kernel
+    if (cfg < 0 || (cfg & ~(0xff | COR_ORDER_REVERSE)) != 0 || !(sel == 0 || sel == 1 || sel == 2 || sel == 3 || sel == 4 || sel == 9 || sel == 13)) return COR_EINVAL;
+#endif
+  }
   if (residual && ldr < N) return COR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (ab_dtype == COR_F32 && c_dtype == COR_F32)

@@ -49,10 +49,11 @@ int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab_dtype,
              const float* bias, int act, const float* col_scale,
              const float* residual, long ldr, int res_row_mod, int cfg, void* stream);
 /* `cfg` is a PER-CALL kernel choice (no process-global state; safe from several threads / streams): 0 = automatic
- * (13 for bf16 operands from 200 output tiles of 256x256 up, else 2, or 1 when K has a ragged tail); low byte 1: 128x128
- * register-staged (any K); 2: 128x128 LDS-DMA; 3 / 4: 128x64 / 64x64; 9: 256x128, three LDS buffers; 13: persistent 256x256
- * ping-pong kernel (bf16 operands; falls back to 2 / 1 where it does not apply); 14: the same on 16x16x32 MFMAs. Bits 8 and up:
- * timing-only ablation / tile-order knobs of the persistent kernel (tools/gemm_ksweep.py); production callers pass 0. */
+ * (13 for bf16 operands from 200 output tiles of 256x256 up, else 2, or 1 when K has a ragged tail); 1: 128x128 register-staged
+ * (any K); 2: 128x128 LDS-DMA; 3 / 4: 128x64 / 64x64; 9: 256x128, three LDS buffers; 13: persistent 256x256 ping-pong kernel
+ * (bf16 operands; falls back to 2 / 1 where it does not apply); optionally | COR_ORDER_REVERSE. Anything else is COR_EINVAL:
+ * the timing probes of the development builds (result-destroying ablation bits, 16x16 MFMA form) are not in this library
+ * (they build into tools/probes/libcor_probes.so with -DCOR_PROBES). */
 
 /* y[r,:] = LayerNorm(x[r,:]) * w + b over the last dim, biased variance.
  * ref: nn.LayerNorm (image_encoder.py:169,183), LayerNorm2d common.py:31-43 and mask_adapter.py:226-251 (on
@@ -88,12 +89,9 @@ int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, cons
  * run time and q is rounded to bf16 once. The rel-pos terms are rescaled accordingly inside (they use the unscaled q).
  * `variant` is a PER-CALL kernel choice for the bf16 MFMA path: 0 = default kernels (global: flash_global_pipe, software-
  * pipelined over key tiles; windowed: win_attn, one 7-wave block per (window, head)); 1 = the round-1 chain forms of the same
- * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py); 2 / 3 = global
- * attention with the biases and the running reference (2) or the row bias and reference only (3) as extra k-steps of the score
- * MFMA (need q_prescale = scale * log2 e; A/B partners, measured 12 % / 1 % slower than 0); 4 = global attention in 8-wave
- * blocks (bit-identical to 0, 5 % slower); 5 = the ping-pong form (8-wave blocks, wave groups one barrier interval apart, matrix and
- * softmax segments alternating; bit-identical to 0, 5 % slower); 6 = row sums of P by a ones-row MFMA (round-1 form, 4 % slower); 9 / 10..14 = timing probes of the default global kernel (cycle counters INSTEAD of outputs:
- * tools/attn_stamps.py only). */
+ * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py);
+ * optionally | COR_ORDER_REVERSE. Anything else is COR_EINVAL (the timing probe of the global kernel, which writes cycle
+ * counters instead of outputs, exists in -DCOR_PROBES builds only: tools/probes/libcor_probes.so, tools/attn_stamps.py). */
 
 /* Which kernel family cor_attention (sam_window = -1) / cor_sam_attention (0 = global, > 0 = windowed) runs for 16-byte-aligned
  * operands of this shape: bf16 with head_dim 64 / 72 / 80 is on the matrix cores. Pure function (no launch). */

@@ -347,60 +347,72 @@ def test_sam_attention_vs_reference_golden(tag):
     report(f"sam_attention_golden_{tag}", y.view(3, S, S, dim), g["y"], rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,H,amp", [(1, 12, 1.0), (3, 16, 1.0), (2, 12, 6.0), (2, 5, 0.05)])
-def test_global_attention_pipelined_vs_chain_kernel(B, H, amp):
-    """flash_global_pipe (software-pipelined, LDS-DMA rings, lazy rescale, MFMA row sums; default) against flash_fwd<1> (one
-    tile at a time, exact running max) on the same inputs: same math, different rounding points (bf16 P is scaled by
-    2^(m_exact - m_lazy) <= 2^8, an exact power of two, so only the row-sum rounding differs). amp = 6 drives score ranges of
-    +-100 (lazy rescale fires often, strong peaks), amp = 0.05 nearly uniform attention."""
+@pytest.mark.parametrize("B,H,amp", [(1, 12, 1.0), (3, 16, 1.0), (2, 12, 6.0), (2, 5, 0.05), (32, 12, 1.0)])
+def test_global_attention_pipelined_vs_fp64_reference_and_chain_kernel(B, H, amp):
+    """flash_global_pipe (software-pipelined, LDS-DMA rings, lazy rescale; default) at T = 4096 keys against
+    (a) an fp64 CPU evaluation of the reference formula (image_encoder.py:225-241,326-362, oracle.sam.rel_pos_bias, pinned by the
+        goldens) on the SAME bf16 operands, for three (image, head) pairs of the launch incl. the last image of the batch-32 case
+        (the benchmarked batch) - not a self-comparison;
+    (b) flash_fwd<1> (one tile at a time, exact running max) on the whole tensor: same math, different rounding points.
+    amp = 6 drives score ranges of +-100 log2 units (lazy rescale fires often, strong peaks), amp = 0.05 nearly uniform attention.
+    Also the q_prescale path the engine runs (scale * log2 e folded into the q third by the caller), both kernel forms."""
     ops, _ = _ops()
     from cor_amd import _native as nat
-    lib = nat.load()
     g = torch.Generator(device=DEV).manual_seed(B * 100 + H)
     d = H * 64
     qkv = (torch.randn((B * 4096, 3 * d), generator=g, device=DEV) * amp).to(BF16)
     pad = torch.randn((3 * d,), generator=g, device=DEV).to(BF16)
     rh = torch.randn((127, 64), generator=g, device=DEV) * 0.3
     rw = torch.randn((127, 64), generator=g, device=DEV) * 0.3
-    ref = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=1)     # chain form (per-call choice)
     out = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32)
-    out2 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32)
-    assert torch.equal(out, out2)                                   # run-to-run reproducible
-    report(f"global_attn_pipe_B{B}_H{H}_amp{amp}", out, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
-    out8 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=4)     # 8-wave blocks: same arithmetic per wave
-    assert torch.equal(out8, out)
-    out6 = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=6)     # row sums by a ones-row MFMA (over the bf16-rounded P)
-    report(f"global_attn_mfma_rowsum_B{B}_H{H}_amp{amp}", out6, out, rtol=0, atol=1e-2 * float(ref.abs().max()))
-    out_pp = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=5)   # ping-pong form: same arithmetic per wave
-    assert torch.equal(out_pp, out)
-    assert torch.equal(out_pp, ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=5))
-    # q_prescale path (what the engine runs): scale * log2 e folded into the q third by the caller; bias and running
-    # reference folded into the score accumulator. One more bf16 rounding on the q side than the chain form (which scales in
-    # fp32): at amp = 6 (|score| ~ 100 log2 units, nearly one-hot softmax) that moves near-ties, hence the wider budget there.
-    from cor_amd import _native as nat
+    assert torch.equal(out, ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32))     # run-to-run reproducible
+    chain = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=F32, variant=1)            # chain form (per-call choice)
     c = nat.Q_PRESCALE_HD64
     qs, ps = qkv.float(), pad.float()
     qs[:, :d] *= c; ps[:d] *= c
     qs, ps = qs.to(BF16), ps.to(BF16)
-    o_p = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)
-    o_p2 = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)
-    assert torch.equal(o_p, o_p2)
-    o_f = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2)    # bias + reference as extra k-steps of the score MFMA
-    assert torch.equal(o_f, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2))
-    r_ff = report(f"global_attn_mfma_fold_vs_fma_form_B{B}_H{H}_amp{amp}", o_f, o_p if False else ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c),
-                  rtol=0, atol=(4e-2 if amp > 2 else 1e-2) * float(ref.abs().max()))
-    assert r_ff["rel_l2"] <= (1e-2 if amp > 2 else 2e-3), r_ff       # same operands: only the bias split (2^-17) and bf16-P rounding points differ
-    o_f1 = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=3)   # row bias - reference folded only
-    assert torch.equal(o_f1, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=3))
-    r_f1 = report(f"global_attn_rowbias_fold_vs_fma_form_B{B}_H{H}_amp{amp}", o_f1, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c),
-                  rtol=0, atol=(4e-2 if amp > 2 else 1e-2) * float(ref.abs().max()))
-    assert r_f1["rel_l2"] <= (1e-2 if amp > 2 else 2e-3), r_f1
-    report(f"global_attn_prescaled_folded_B{B}_H{H}_amp{amp}", o_f, ref, rtol=8e-2 if amp > 2 else 2e-2, atol=(8e-2 if amp > 2 else 2e-2) * float(ref.abs().max()))
-    tol = 8e-2 if amp > 2 else 2e-2
-    r_p = report(f"global_attn_prescaled_B{B}_H{H}_amp{amp}", o_p, ref, rtol=tol, atol=tol * float(ref.abs().max()))
-    assert r_p["rel_l2"] <= (2e-2 if amp > 2 else 5e-3), r_p
-    o_c = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=1)    # chain form, prescaled input
-    report(f"global_attn_prescaled_chain_B{B}_H{H}_amp{amp}", o_c, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+    o_p = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)             # what the engine runs
+    assert torch.equal(o_p, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c))
+    o_c = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=1)
+    hard = amp > 2
+    # (a) fp64 reference on sampled (image, head) pairs
+    x = qkv.view(B, 4096, 3, H, 64)
+    rhd, rwd = rh.to(BF16).double().cpu(), rw.to(BF16).double().cpu()                            # the kernels feed the tables to the MFMA in bf16
+    pairs = sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2)})
+    worst = {}
+    for (b, hh) in pairs:
+        q, k, v = (x[b, :, j, hh].double().cpu() for j in range(3))
+        bias = osam.rel_pos_bias(q[None], rhd, rwd, 64)[0]
+        ref = torch.softmax((q * 0.125) @ k.T + bias, dim=-1) @ v
+        scale = float(ref.abs().max())
+        for name, got, tol, rl in (("pipe", out, 2e-2, 4e-3), ("chain", chain, 2e-2, 4e-3), ("pipe_prescaled", o_p, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3),
+                                   ("chain_prescaled", o_c, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3)):
+            r = report(f"global_attn_{name}_vs_fp64_B{B}_H{H}_amp{amp}_b{b}_h{hh}", got.view(B, 4096, H, 64)[b, :, hh], ref.float(), rtol=0, atol=tol * scale)
+            assert r["rel_l2"] <= rl * max(1.0, amp if not hard else 1.0), (name, b, hh, r)
+            worst[name] = max(worst.get(name, 0.0), r["rel_l2"])
+    _note(name=f"global_attn_vs_fp64_relL2_B{B}_H{H}_amp{amp}", pairs=len(pairs), **worst)
+    # (b) the two kernel forms against each other on the whole tensor
+    report(f"global_attn_pipe_vs_chain_B{B}_H{H}_amp{amp}", out, chain, rtol=2e-2, atol=2e-2 * float(chain.abs().max()))
+    tol = 8e-2 if hard else 2e-2
+    r_p = report(f"global_attn_prescaled_vs_chain_B{B}_H{H}_amp{amp}", o_p, chain, rtol=tol, atol=tol * float(chain.abs().max()))
+    assert r_p["rel_l2"] <= (2e-2 if hard else 5e-3), r_p
+
+
+def test_production_library_rejects_probe_and_experimental_selectors():
+    """The timing probes (cycle counters INSTEAD of outputs) and the result-destroying GEMM ablation bits of round 2 live in the
+    COR_PROBES build only (make -C cor_amd/csrc probes): the production ABI answers COR_EINVAL instead of silent garbage."""
+    from cor_amd import _native as nat
+    ops, _ = _ops()
+    qkv = torch.zeros((4096, 3 * 64), device=DEV, dtype=BF16)
+    rel = torch.zeros((127, 64), device=DEV)
+    for variant in (2, 3, 4, 5, 6, 9, 10, 14, 77):
+        with pytest.raises(nat.NativeError):
+            ops.sam_attention(qkv, None, rel, rel, 1, 1, 64, 0, variant=variant)
+    a = torch.zeros((256, 128), device=DEV, dtype=BF16)
+    for cfg in (1 << 8, 2 << 8, 4 << 8, 8 << 8, 13 | (1 << 8), 14, 5, 200):
+        with pytest.raises(nat.NativeError):
+            ops.gemm(a, a, cfg=cfg)
+    assert ops.gemm(a, a, cfg=2).shape == (256, 256) and ops.gemm(a, a, cfg=13).shape == (256, 256)
 
 
 @pytest.mark.parametrize("B,H,grid,amp,TO", [(1, 12, 64, 1.0, BF16), (3, 16, 64, 1.0, F32), (2, 5, 64, 6.0, BF16), (2, 12, 64, 0.05, BF16),
@@ -755,6 +767,49 @@ def test_full_depth_bf16_vs_reference_golden_with_counts(pooling):
     _note(name=f"full_depth_bf16_retrieval_{pooling}", recall_at_1_vs_fp32_oracle=rec1, planted_is_top1=bool(ri[0, 0] == where),
           top10_index_mismatches=mism, of=10, max_score_diff=float((s_b.cpu() - rs).abs().max()))
     assert ri[0, 0] == where and rec1 == 1.0
+
+
+def test_batch32_bf16_vs_fp32_exact_mode_anchored_to_the_golden():
+    """The benchmarked configuration's kernels (batch 32: persistent 256x256 GEMM, pipelined global attention, windowed block
+    kernel, hipGraph-free eager launches) against the exact-fp32 HIP mode on the SAME 32 samples, with the fp32 mode itself
+    pinned to the reference: sample 0 is the golden input of tests/golden/toplevel_MaskAdapterPooling.npz and its fp32 outputs
+    must match the reference's (1e-3). Per-sample budgets for bf16 vs fp32 (the reference's own bf16-autocast error on this
+    model is emb rel-L2 4.8e-2, masks 2.7e-2, 0.8 % sign flips: tests/golden/toplevel_autocast_bf16_*.npz):
+    emb rel-L2 <= 3e-2, feat rel-L2 <= 1e-2, masks rel-L2 <= 6e-2, mask-sign flips <= 2 %, IoU-argmax flips reported."""
+    from cor_amd import config
+    g = load("toplevel_MaskAdapterPooling")
+    gcfg = dict(config.siglip_cfg("ViT-B-16-SigLIP-384"), depth=2, t_depth=2, vocab=512)
+    model = _build(12, (2, 5, 8, 11), gcfg, "MaskAdapterPooling")
+    spec = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = ocfg.random_state({k: v for k, v in spec.items() if "attn_pool" not in k}, int(g["seed_params"]))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).eval()
+    B = 32
+    gold = make_inputs(int(g["seed_inputs"]), q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 512), mask=("mask", 1, 384))
+    rest = make_inputs(4242, q=(B - 1, 3, 1024, 1024), s=(B - 1, 3, 384, 384), text=("tokens", B - 1, 64, 512), mask=("mask", B - 1, 384))
+    kw = dict(query_image_inputs=torch.cat([gold["q"], rest["q"]]).to(DEV), support_image_inputs=torch.cat([gold["s"], rest["s"]]).to(DEV),
+              change_text_inputs=torch.cat([gold["text"], rest["text"]]).to(DEV), support_mask_inputs=torch.cat([gold["mask"], rest["mask"]]).to(DEV))
+    model.compute_dtype = F32
+    parts = [model.forward_with_aux(**{k: v[i:i + 8] for k, v in kw.items()}, multimask_output=True) for i in range(0, B, 8)]
+    m32, e32, f32_ = (torch.cat([p[j] for p in parts]) for j in range(3))
+    best32 = torch.cat([p[3]["best"] for p in parts])
+    es = float(np.abs(g["emb"]).max())
+    report("batch32_fp32_sample0_emb_vs_reference_golden", e32[0:1, :, ::4, ::4], g["emb"], rtol=0, atol=1e-3 * es)
+    report("batch32_fp32_sample0_masks_vs_reference_golden", m32[0:1, :, ::4, ::4], g["masks_1"], rtol=0, atol=1e-3 * float(np.abs(g["masks_1"]).max()))
+    report("batch32_fp32_sample0_feat_vs_reference_golden", f32_[0:1], g["feat"], rtol=0, atol=1e-5)
+    model.compute_dtype = BF16
+    m16, e16, f16_, aux16 = model.forward_with_aux(**kw, multimask_output=True)
+    rel = lambda a, b: ((a.float() - b.float()).flatten(1).norm(dim=1) / b.float().flatten(1).norm(dim=1))
+    r_e, r_f, r_m = rel(e16, e32), rel(f16_, f32_), rel(m16, m32)
+    flips = ((m16 > 0) != (m32 > 0)).flatten(1).float().mean(dim=1)
+    argmax_flips = int((aux16["best"] != best32).sum())
+    _note(name="batch32_bf16_vs_fp32_exact_mode", emb_rel_l2_max=float(r_e.max()), emb_rel_l2_mean=float(r_e.mean()), feat_rel_l2_max=float(r_f.max()),
+          masks_rel_l2_max=float(r_m.max()), masks_rel_l2_mean=float(r_m.mean()), mask_sign_flip_fraction_max=float(flips.max()),
+          mask_sign_flip_fraction_mean=float(flips.mean()), iou_argmax_flips=argmax_flips, of=B)
+    assert float(r_e.max()) <= 3e-2 and float(r_f.max()) <= 1e-2, (r_e.max(), r_f.max())
+    same = aux16["best"] == best32                                   # a flipped IoU argmax selects another mask channel: compare like with like
+    assert float(r_m[same].max()) <= 6e-2 and float(flips[same].max()) <= 0.02, (r_m[same].max(), flips[same].max())
+    assert argmax_flips <= 1, argmax_flips
 
 
 def test_siglip_towers_vs_oracle():

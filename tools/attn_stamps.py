@@ -5,7 +5,8 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from cor_amd import ops
+from cor_amd import ops, _native
+_native.use_probe_library()     # variant 9 (cycle stamps instead of outputs) exists in the COR_PROBES build only: make -C cor_amd/csrc probes
 from cor_amd._native import Q_PRESCALE_HD64 as QC
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 H, g, dev, T = 12, 64, "cuda:0", torch.bfloat16
@@ -18,12 +19,11 @@ for _ in range(30):
     ops.sam_attention(qkv, pad, rh, rw, B, H, g, 0, q_prescale=QC)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-PP = len(sys.argv) > 2 and sys.argv[2] == "pp"            # ping-pong form (variant 10) instead of the default kernel (variant 9)
-e0.record(); out = ops.sam_attention(qkv, pad, rh, rw, B, H, g, 0, q_prescale=QC, variant=(10 + (int(sys.argv[3]) if len(sys.argv) > 3 else 0)) if PP else 9); e1.record(); torch.cuda.synchronize()
-nw = 8 if PP else 4
+e0.record(); out = ops.sam_attention(qkv, pad, rh, rw, B, H, g, 0, q_prescale=QC, variant=9); e1.record(); torch.cuda.synchronize()
+nw = 4
 nblk = (g * g // (32 * nw)) * H * B
 st = out.view(torch.int64).flatten()[: nblk * nw * 8].view(nblk * nw, 8)[:, :6].double()
-names = ["dma_issue", "M_segment", "barrier_after_M", "V_segment", "vmcnt_wait", "barrier_after_V"] if PP else ["dma_issue", "phase_A(PV+max)", "ref_update", "phase_B(QK+exp)", "vmcnt_wait", "barrier"]
+names = ["dma_issue", "phase_A(PV+max)", "ref_update", "phase_B(QK+exp)", "vmcnt_wait", "barrier"]
 per_tile = st.mean(0) / 64.0
 tot = float(per_tile.sum())
 print(json.dumps(dict(kernel_ms_probe=e0.elapsed_time(e1), cycles_per_tile_total=tot,

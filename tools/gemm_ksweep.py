@@ -4,7 +4,8 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from cor_amd import ops, _native
+from cor_amd import ops, _native as _nat
+_nat.use_probe_library()        # ablation knobs (bits 8.. of cfg) exist in the COR_PROBES build only: make -C cor_amd/csrc probes, _native
 lib = _native.load(); dev = "cuda:0"; T = torch.bfloat16
 cfgs = [int(c) for c in sys.argv[1:]] or [2, 3]   # 7xx = persistent kernel with ablation knob xx (1 no stores, 2 no epilogue, 4 no MFMA)
 M, N = 131072, 768
