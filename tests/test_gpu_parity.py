@@ -183,6 +183,53 @@ def test_gemm_pingpong_guard_rows_and_fallbacks():
     report("gemm_pp_fallback_ktail", ops.gemm(a2, w2, out_dtype=F32)[:256], a2[:256].float() @ w2.float().T, rtol=1e-4, atol=2e-4)
 
 
+def test_configs3_shapes_kernel_by_kernel():
+    """BASELINE configs[3] (SAM-L + SigLIP-L/16, batch 64) launches its kernels at M = 262 144 rows: the first full-size run of
+    that configuration in round 2 ended in a process abort at the first synchronisation after the forward (gpurun_out/pytest_a.log,
+    08:24; cause not recoverable from the log). This test runs every large launch of that forward ALONE
+    at exactly those shapes and checks sampled rows against torch / fp64 references, with a synchronisation after each, so that a
+    device-side failure is pinned to ONE launch: byte offsets there reach 2^31 (lin1 output, lin2 A operand), 32-bit offset
+    arithmetic is host-checked to stay below 2^32."""
+    ops, _ = _ops()
+    M, d, H = 64 * 4096, 1024, 16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rows = torch.cat([torch.arange(0, 256), torch.arange(M - 256, M), torch.randint(0, M, (256,))]).to(DEV)
+    x = torch.randn((M, d), generator=g, device=DEV)
+    lnw, lnb = torch.rand((d,), generator=g, device=DEV) + 0.5, torch.randn((d,), generator=g, device=DEV) * 0.1
+    h = ops.layernorm(x, lnw, lnb, 1e-6, out_dtype=BF16, reverse=True); torch.cuda.synchronize()
+    report("cfg3_layernorm_262144x1024", h[rows], torch.nn.functional.layer_norm(x[rows], (d,), lnw, lnb, 1e-6), rtol=1e-2, atol=2e-2)
+    def lin(n, k):
+        return (torch.randn((n, k), generator=g, device=DEV) / math.sqrt(k)).to(BF16), torch.randn((n,), generator=g, device=DEV) * 0.1
+    for name, n, k, kind in (("qkv", 3 * d, d, "bf16"), ("proj_res", d, d, "res"), ("lin1_gelu", 4 * d, d, "gelu"), ("lin2_res", d, 4 * d, "res")):
+        w, b = lin(n, k)
+        a = h if k == d else torch.randn((M, k), generator=g, device=DEV).to(BF16)
+        z = a[rows].float() @ w.float().T + b
+        if kind == "res":
+            xr = x.clone()
+            ops.gemm(a, w, out_dtype=F32, bias=b, residual=xr, out=xr); torch.cuda.synchronize()
+            report(f"cfg3_gemm_{name}_262144x{n}x{k}", xr[rows], z + x[rows], rtol=1e-4, atol=2e-3)
+            del xr
+        else:
+            y = ops.gemm(a, w, out_dtype=BF16, bias=b, act=ops.ACT_GELU_ERF if kind == "gelu" else ops.ACT_NONE, reverse=(kind == "gelu")); torch.cuda.synchronize()
+            report(f"cfg3_gemm_{name}_262144x{n}x{k}", y[rows], torch.nn.functional.gelu(z) if kind == "gelu" else z, rtol=1e-2, atol=3e-2)
+            if name == "qkv":
+                qkv = y
+        del a, w
+    pad = torch.randn((3 * d,), generator=g, device=DEV).to(BF16)
+    for win, S in ((14, 14), (0, 64)):
+        rh, rw = torch.randn((2 * S - 1, 64), generator=g, device=DEV) * 0.3, torch.randn((2 * S - 1, 64), generator=g, device=DEV) * 0.3
+        o = ops.sam_attention(qkv, pad, rh, rw, 64, H, 64, win, reverse=True); torch.cuda.synchronize()
+        o1 = ops.sam_attention(qkv, pad, rh, rw, 64, H, 64, win, variant=1); torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all()
+        report(f"cfg3_sam_attention_window{win}_B64_H16", o, o1, rtol=2e-2, atol=2e-2 * float(o1.float().abs().max()))
+        if win == 0:                                   # fp64 reference for the LAST image and head (largest offsets)
+            xq = qkv.view(64, 4096, 3, H, 64)
+            q, k, v = (xq[63, :, j, H - 1].double().cpu() for j in range(3))
+            bias = osam.rel_pos_bias(q[None], rh.to(BF16).double().cpu(), rw.to(BF16).double().cpu(), 64)[0]
+            ref = torch.softmax((q * 0.125) @ k.T + bias, dim=-1) @ v
+            report("cfg3_global_attention_b63_h15_vs_fp64", o.view(64, 4096, H, 64)[63, :, H - 1], ref.float(), rtol=0, atol=2e-2 * float(ref.abs().max()))
+
+
 # ======================================================================================================
 # row kernels
 # ======================================================================================================
