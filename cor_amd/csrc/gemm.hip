@@ -46,6 +46,7 @@ struct GemmArgs {
   int dbg;             // timing-only ablation knobs (tools/gemm_ksweep.py): 1 no C stores, 2 no epilogue, 4 no MFMA
   int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
   int rev;             // 1: walk the tile order backwards (COR_ORDER_REVERSE: start where the producer of A finished)
+  int order;           // persistent kernel: 1 = XCD-stationary W-panels (default), 0 = round-2 banded order (COR_PROBES A/B: cfg bit 20)
 };
 
 template <typename TA> struct Mfma;
@@ -486,11 +487,32 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 
   unsigned oa[4], ob[4];                            // per-lane byte offsets of the four 64-row blocks (rows clamped at the edge)
   int m0 = 0, n0 = 0;
+  // Tile order. g.order == 1 (N <= 1024, chosen by the host): every XCD owns a CONTIGUOUS range of the order "N-panel group (4 panels), M-panel, N-panel
+  // in group": the 32 blocks of an XCD work, step after step, on 8 consecutive M-panels x the SAME 4 W-panels, so the W-panels stay
+  // in that XCD's 4-MiB L2 for a whole sweep over M and only the A-panels stream (N = 768: one group, every A-panel is fetched once).
+  // The round-2 order (g.order == 0: bands of GM M-panels, tiles dealt to the XCDs in chunks of 32 per step of 256) gave every XCD
+  // 8 new A-panels AND 4 new W-panels at every step: L2 read traffic 4.2x (qkv, lin1) / 1.5x (lin2) the algorithmic bytes
+  // (FETCH_SIZE, profiles/r03_gemm_pmc_by_shape.jsonl).
+  const int per_xcd = (total + 7) >> 3;
+  auto tile_of = [&](int q) -> int {               // q-th tile of this block, or -1
+    if (g.order == 0) { const int t = xcd_remap(blockIdx.x, G) + q * G; return t < total ? t : -1; }
+    const int x = blockIdx.x & 7, t = x * per_xcd + q * (G >> 3) + (blockIdx.x >> 3);
+    return t < min((x + 1) * per_xcd, total) ? t : -1;
+  };
   auto set_tile = [&](int Lf) {
     const int L = g.rev ? g.tm * g.tn - 1 - Lf : Lf;
-    const int band = L / (GM * g.tn), rem = L - band * (GM * g.tn);
-    const int gm_eff = min(GM, g.tm - band * GM);
-    m0 = (band * GM + rem % gm_eff) * BM; n0 = (rem / gm_eff) * BN;
+    if (g.order == 0) {
+      const int band = L / (GM * g.tn), rem = L - band * (GM * g.tn);
+      const int gm_eff = min(GM, g.tm - band * GM);
+      m0 = (band * GM + rem % gm_eff) * BM; n0 = (rem / gm_eff) * BN;
+    } else {
+      constexpr int GW = 4;
+      const int full = g.tn / GW, nfull = full * g.tm * GW;
+      int mp, np;
+      if (L < nfull) { const int ng = L / (g.tm * GW), r2 = L - ng * (g.tm * GW); mp = r2 / GW; np = ng * GW + (r2 - mp * GW); }
+      else { const int tw = g.tn - full * GW, r2 = L - nfull; mp = r2 / tw; np = full * GW + (r2 - mp * tw); }
+      m0 = mp * BM; n0 = np * BN;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       oa[j] = (unsigned)((long)min(m0 + srow + 64 * j, g.M - 1) * g.lda_b + sch);   // < 4 GB (host-checked)
@@ -518,8 +540,9 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
     if (nkt > 1) { issue_a(0, 1, 2); issue_a(1, 1, 3); issue_b(0, 1, 8); issue_b(1, 1, 9); }
   };
 
-  int L = xcd_remap(blockIdx.x, G);                 // G % 8 == 0 (host): tiles L, L + G, ...
-  if (L >= total) return;
+  int qi = 0;                                       // G % 8 == 0 (host); this block's tiles: tile_of(0), tile_of(1), ...
+  int L = tile_of(0);
+  if (L < 0) return;
   set_tile(L);
   prologue();
   bool stores_pending = false;
@@ -643,8 +666,8 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
     if (wr == 0) COR_BAR();                          // realign the two wave rows; the ring is idle from here
 
     const int cm0 = m0, cn0 = n0;
-    const int Ln = L + G;
-    if (Ln < total) {
+    const int Ln = tile_of(++qi);
+    if (Ln >= 0) {
       set_tile(Ln);
       prologue();
     }
@@ -689,7 +712,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
       default: COR_EPI(COR_ACT_NONE) break;
     }
 #undef COR_EPI
-    if (Ln >= total) break;
+    if (Ln < 0) break;
     L = Ln;
     stores_pending = !COR_DBG(g, 2);
   }
@@ -766,8 +789,9 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
   g.M = M; g.N = N; g.Kb = (int)(K * esz);
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
-  g.dbg = g_gemm_dbg; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
-  g.group_m = (g_gemm_dbg >> 4) ? (g_gemm_dbg >> 4) : 8;
+  g.dbg = g_gemm_dbg & 0xfff; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
+  g.order = 1;                                       // resolved below (persistent kernel only): see set_tile
+  g.group_m = ((g_gemm_dbg >> 4) & 0xff) ? ((g_gemm_dbg >> 4) & 0xff) : 8;
   const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   g.vec_epi = (N % 4 == 0) && (N >= 8) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
               (!residual || (al16(residual) && ldr % 4 == 0));
@@ -790,6 +814,13 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     if (!ok) cfg = k128 ? 2 : 1;
     else if constexpr (sizeof(TA) == 2) {
       g.tm = cdiv(g.M, 256); g.tn = cdiv(g.N, 256);
+      // XCD-stationary order where all N-panels form ONE group (N <= 1024: proj / lin2 / patch embed): every A-panel is fetched
+      // once (L2 read traffic 1.39 -> 1.17x / 1.16 -> 1.07x of the algorithmic bytes at equal time). Wider GEMMs keep the banded order:
+      // there the W-panels do not survive in L2 beside the A and C streams, the L2 traffic is unchanged (1.7-1.8x, served by the
+      // Infinity Cache: the XCDs of a band fetch the same A-panels at the same time) and the sweeps of different XCDs over M drift
+      // apart, which costs 2-5 % (tools/gemm_order_ab.py, profiles/r03_gemm_tile_order_ab.jsonl).
+      g.order = g.tn <= 4 ? 1 : 0;
+      if (g_gemm_dbg & 0x1000) g.order ^= 1;         // COR_PROBES A/B (cfg bit 20); production callers cannot set it
       static DevOnce once_a;
       const int n_cu = cor_device_cus();
       cor_max_dyn_lds((const void*)gemm_pp<TO, false>, 163840, once_a);

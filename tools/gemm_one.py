@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops, _native
+if len(sys.argv) > 4 and int(sys.argv[4]) >> 8:      # ablation / order bits: only the COR_PROBES build accepts them
+    _native.use_probe_library()
 M, N, K = (int(v) for v in sys.argv[1:4]); cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 mode = sys.argv[5] if len(sys.argv) > 5 else "plain"
 A = torch.randn((M, K), device="cuda").to(torch.bfloat16); W = (torch.randn((N, K), device="cuda") / K ** 0.5).to(torch.bfloat16)

@@ -1,0 +1,36 @@
+#!/bin/bash
+# FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc passes) of the four SAM-B block GEMMs at batch 32, per shape.
+# usage: tools/measure_r03_gemm_pmc.sh [extra gemm_one cfg]   -> gpurun_out/gpmc/summary.txt
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/gpmc; mkdir -p $O
+CFG=${1:-0}
+cd /tmp; export TMPDIR=/tmp
+run() { # tag M N K mode
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/$1_$C -- python3 $R/tools/gemm_one.py $2 $3 $4 $CFG $5 > /dev/null 2>$O/$1_$C.err || { echo "FAILED $1 $C"; tail -3 $O/$1_$C.err; return 1; }
+  done
+}
+run qkv 131072 2304 768 plain || exit 1
+run lin1 131072 3072 768 gelu || exit 1
+run lin2 131072 768 3072 res || exit 1
+run proj 131072 768 768 res || exit 1
+cd $R
+python3 - <<PY > $O/summary_$CFG.txt
+import csv, glob, json
+alg = {"qkv": (131072*768*2 + 2304*768*2, 131072*2304*2), "lin1": (131072*768*2 + 3072*768*2, 131072*3072*2),
+       "lin2": (131072*3072*2 + 768*3072*2 + 131072*768*4, 131072*768*4), "proj": (131072*768*2 + 768*768*2 + 131072*768*4, 131072*768*4)}
+for tag in ("qkv", "lin1", "lin2", "proj"):
+    v = {}
+    for C in ("FETCH_SIZE", "WRITE_SIZE"):
+        tot, n = 0.0, 0
+        for f in glob.glob(f"$O/{tag}_{C}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "gemm" in r["Kernel_Name"] and r["Counter_Name"] == C:
+                    tot += float(r["Counter_Value"]); n += 1
+        v[C] = tot / max(n, 1) * 1024
+    rd, wr = 2 * v["FETCH_SIZE"], v["WRITE_SIZE"]          # FETCH_SIZE doubled: gfx950 correction (MI355X guide, HBM section)
+    print(json.dumps(dict(shape=tag, cfg="$CFG", read_MB=round(rd / 1e6, 1), write_MB=round(wr / 1e6, 1), alg_read_MB=round(alg[tag][0] / 1e6, 1),
+                          alg_write_MB=round(alg[tag][1] / 1e6, 1), ratio=round((rd + wr) / (alg[tag][0] + alg[tag][1]), 3))))
+PY
+cat $O/summary_$CFG.txt
