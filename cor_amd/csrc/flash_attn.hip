@@ -567,18 +567,22 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   // and rho+2 share their banks (2-way conflict on every V read: SQ_LDS_BANK_CONFLICT was 30 % of the kernel's LDS cycles). Rows
   // with bit 1 set store their two 64-byte halves exchanged (source chunk ^ 4), the reader picks window db ^ bit 1 of its row.
   const int vswz = (sch ^ (((srow >> 1) & 1) << 2)) * 8;
-  const bf16_t* kv0 = kvbase + (long)srow * a.d3;           // row srow of tile 0; + 32*d3 for the second chunk
+  // "saddr" copies: wave-uniform 64-bit tile base (SGPRs, one scalar add per tile) + per-lane 32-bit byte offsets that never change
+  // (row srow / 32 + srow of a tile, K or V plane, swizzled chunk): no vector address arithmetic per copy
+  const unsigned vk0 = (unsigned)((srow * a.d3 + a.H * 64 + kswz) * 2), vk1 = vk0 + (unsigned)(32 * a.d3 * 2);
+  const unsigned vv0 = (unsigned)((srow * a.d3 + 2 * a.H * 64 + vswz) * 2), vv1 = vv0 + (unsigned)(32 * a.d3 * 2);
+  const long tile_bytes = (long)KT * a.d3 * 2;
   auto issue_k = [&](int t, int slot) {
-    const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + a.H * 64 + kswz;
+    const char* base = (const char*)kvbase + (long)min(t, nt - 1) * tile_bytes;
     const unsigned d = lds0 + slot * TILE_B + wofs;
-    glds16(p0, d);
-    glds16(p0 + 32L * a.d3, d + 4096);
+    glds16_so(base, vk0, d);
+    glds16_so(base, vk1, d + 4096);
   };
   auto issue_v = [&](int t, int slot) {
-    const bf16_t* p0 = kv0 + (long)min(t, nt - 1) * KT * a.d3 + 2 * a.H * 64 + vswz;
+    const char* base = (const char*)kvbase + (long)min(t, nt - 1) * tile_bytes;
     const unsigned d = lds0 + K_BYTES + slot * TILE_B + wofs;
-    glds16(p0, d);
-    glds16(p0 + 32L * a.d3, d + 4096);
+    glds16_so(base, vv0, d);
+    glds16_so(base, vv1, d + 4096);
   };
   issue_k(0, 0); issue_k(1, 1); issue_k(2, 2); issue_v(0, 0);
   *(uint4*)(Vring + 2 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 2)
