@@ -911,6 +911,35 @@ def test_similarity_topk(Bq, Ng, k, gdt):
         assert (i[:, Ng:] == -1).all() and torch.isinf(s[:, Ng:]).all()
 
 
+@pytest.mark.parametrize("Bq,Ng,gdt,name", [(256, 100000, BF16, "configs[2]: 100k bf16 gallery, 8 shards of 12.5k, 8 x 32 queries"),
+                                            (512, 1000000, torch.float16, "configs[4]: 1M fp16 gallery, 8 shards of 125k, 8 x 64 queries")])
+def test_eight_way_sharded_search_equals_the_unsharded_oracle(Bq, Ng, gdt, name):
+    """BASELINE configs[2] / configs[4] without the 8-GPU node: the gallery is cut into the 8 row shards shard_bounds() gives the 8
+    ranks, every shard is searched on THIS GPU with its global offset by the same kernels a rank would run (all Bq all-gathered
+    queries against its 12.5k / 125k rows), and the 8 packed lists go through the product's pack -> unpack -> merge_topk_host path.
+    The merged top-10 must be BITWISE (scores and indices) the CPU chain oracle's over the whole gallery, duplicates across shard
+    borders included. (What this cannot show is the RCCL transport itself: gloo world-2/-4 tests cover the collective logic.)"""
+    from cor_amd import retrieval
+    k = 10
+    rng = np.random.default_rng(Bq + Ng)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Bq, 256), dtype=np.float32)), dim=-1)
+    G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Ng, 256), dtype=np.float32)), dim=-1).to(gdt)
+    per = -(-Ng // 8)
+    G[per] = G[per - 1]; G[5 * per + 3] = G[17]; G[Ng - 1] = G[17]                 # ties across shard borders / far-apart shards
+    Gd = G.to(DEV)
+    parts = []
+    for r in range(8):
+        lo, hi = retrieval.shard_bounds(Ng, 8, r)
+        s_r, i_r = retrieval.GalleryShard(Gd[lo:hi], lo).search(Q.to(DEV), k)
+        parts.append(retrieval._pack_lists(s_r, i_r).cpu())                          # what a rank sends in the gather
+    ps, pi = retrieval._unpack_lists(torch.stack(parts))
+    ms, mi = retrieval.merge_topk_host(list(ps), list(pi), k)
+    rs, ri = oret.similarity_topk_chain(Q.to(gdt).float(), G.float(), k)
+    mism = int((mi != ri).sum()); bits = int((ms.view(torch.int32) != rs.view(torch.int32)).sum())
+    _note(name=f"eight_way_sharded_search_{Bq}x{Ng}_{gdt}", what=name, index_mismatches=mism, score_bit_mismatches=bits, entries=int(ri.numel()))
+    assert mism == 0 and bits == 0, (mism, bits)
+
+
 def test_similarity_topk_lists_fallback_kernels():
     """The per-lane sorted-list kernels (COR_TOPK_FORCE_LISTS; what the device-side fallback runs after an overflow) rank by
     the 16-bit MFMA score: indices equal the chain oracle's except inside fp32-summation-order ties (counted)."""
