@@ -1587,3 +1587,24 @@ def test_graph_captured_forward_equals_eager(mode):
         next(model.parameters()).add_(1.0)
     with pytest.raises(RuntimeError):
         g(**b0)
+
+
+def test_bench_contract_smoke(tmp_path):
+    """bench.py end to end at a reduced batch (the driver runs the default line at round end): ONE JSON line with the contract's keys,
+    `roofline` and `cpu_baseline` objects, recall over all queries with the planted positives found by both pipelines."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "4", "--gallery", "20000", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "recall"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and 0 < d["roofline"]["frac"] < 1
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    rec = d["recall"]
+    assert rec["queries"] == 4 and rec["oracle_recall_at_1_planted"] == 1.0 and rec["recall_at_1"] == 1.0 and rec["max_pairwise_cos"] < 0.9
+
