@@ -19,7 +19,6 @@
 //   * gemm_pp (further down): persistent 256x256 ping-pong kernel for >= 200 output tiles (see its own header);
 //   * XCD-aware tile order: blocks that share an XCD walk N-tiles of the same A row-panel (L2 reuse of A).
 #include "common.h"
-#include <type_traits>
 
 // Timing-only ablation knobs (no C stores / no epilogue / no MFMA / no LDS-DMA issue, tile-order band height, 16x16x32 MFMAs) exist
 // in COR_PROBES builds only (make probes -> tools/probes/libcor_probes.so, used by tools/gemm_ksweep.py): they destroy results, so
@@ -363,12 +362,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   typedef float f32x2_v __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_v){a, b}, bf16x2_v));   // one v_cvt_pk_bf16_f32
 }
-template <typename TO, int MI, int NJ, int ACT, bool HAS_RES, int DEPTH = 0, typename FILL>
+template <typename TO, int MI, int NJ, int ACT, bool HAS_RES, typename FILL>
 __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const GemmArgs& g, __amdgpu_buffer_rsrc_t crs,
                                                 int mbase, int nbase, int lane) {
   constexpr int VW = sizeof(TO) == 2 ? 8 : 4;
   constexpr int CV = 32 / VW, RPP = 64 / CV, PASS = 32 / RPP, Q4 = VW / 4;   // bf16: 4 lanes/row, 16 rows/pass, 2 passes
-  constexpr int NB = MI * NJ, D = DEPTH > 0 ? (HAS_RES ? DEPTH : 1) : ((HAS_RES && sizeof(TO) == 4) ? 2 : 1);       // residual prefetch depth (4, or 2 with bf16 C: spills into the K loop)
+  constexpr int NB = MI * NJ, D = (HAS_RES && sizeof(TO) == 4) ? 2 : 1;       // residual prefetch depth (4, or 2 with bf16 C: spills into the K loop)
   const int cv = lane % CV, row0 = lane / CV;
   // Residual loads run D blocks ahead of their use (the K-loop fragment registers are free here): one block at a time, each
   // block waited for its own HBM round trip and - VMEM retiring in order - for the previous block's stores, eight times per
@@ -719,221 +718,6 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent 256x256 kernel at ONE wave per SIMD (bf16 operands), cfg 15: 256 threads = 4 waves as 2 (M) x 2 (N), a wave owns
-// 128x128 = 4x4 MFMA 32x32 tiles in 256 accumulator registers of its 512-register budget. Same LDS image, ring (A three K-tiles
-// deep, B two), XCD tile orders, epilogue arithmetic and per-k-step accumulation order as gemm_pp (bit-identical results). What
-// differs: no second wave on the SIMD to alternate with - the K-tile is software-pipelined inside ONE instruction stream: each of
-// its four k16 steps is four groups of {2 ds_read_b128 of the NEXT step's fragments, 1 LDS-DMA, 4 MFMAs} pinned by scheduling
-// fences (two vector-memory / LDS instructions per MFMA gap hide behind the matrix pipe), one counted wait + ONE workgroup barrier
-// per K-tile (at its last step, before the first fragments of the next K-tile are read). The 256 spare registers hold the
-// double-buffered fragments (64) and a four-block-deep residual prefetch (64) in the epilogue.
-template <typename TO>
-__global__ void __launch_bounds__(256, 1) gemm_w4(const GemmArgs g) {
-  constexpr int HT = 16384;
-  constexpr int MI = 4, NJ = 4, WTM = 128, WTN = 128;
-  constexpr int VW = sizeof(TO) == 2 ? 8 : 4;
-  constexpr int NSTORE = MI * NJ * (32 / (64 / (32 / VW)));           // buffer stores per wave per tile: 32 (bf16) / 64 (fp32)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
-  // staging map: DMA instruction i (0..3) of a half-tile copies rows 32 wave + 8 i + (lane >> 3), slot lane & 7 <- source chunk
-  // (lane & 7) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4 i + (lane >> 4)) & 7
-  const int srow = 32 * wave + (lane >> 3);
-  // fragment read map (as gemm_pp): lane (r, h) reads chunk (2 s + h) ^ ((r >> 1) & 7) of row 32 blk + r
-  const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
-  int chs[4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) chs[s4] = ((2 * s4 + h) ^ sw) << 4;
-  const int frow = r * 128;
-
-  const int nkt = g.Kb / 128;
-  const int total = g.tm * g.tn, G = gridDim.x;
-  const int GM = g.group_m;
-  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-      g.C, 0, (int)(unsigned)((((long)g.M - 1) * g.ldc + g.N) * (long)sizeof(TO)), 0x00020000);
-
-  unsigned oa[2][4], ob[2][4];                      // per-lane byte offsets of the wave's 8 rows per DMA instruction (rows clamped at the edge)
-  int m0 = 0, n0 = 0;
-  const int per_xcd = (total + 7) >> 3;
-  auto tile_of = [&](int q) -> int {
-    if (g.order == 0) { const int t = xcd_remap(blockIdx.x, G) + q * G; return t < total ? t : -1; }
-    const int x = blockIdx.x & 7, t = x * per_xcd + q * (G >> 3) + (blockIdx.x >> 3);
-    return t < min((x + 1) * per_xcd, total) ? t : -1;
-  };
-  auto set_tile = [&](int Lf) {
-    const int L = g.rev ? g.tm * g.tn - 1 - Lf : Lf;
-    if (g.order == 0) {
-      const int band = L / (GM * g.tn), rem = L - band * (GM * g.tn);
-      const int gm_eff = min(GM, g.tm - band * GM);
-      m0 = (band * GM + rem % gm_eff) * 256; n0 = (rem / gm_eff) * 256;
-    } else {
-      constexpr int GW = 4;
-      const int full = g.tn / GW, nfull = full * g.tm * GW;
-      int mp, np;
-      if (L < nfull) { const int ng = L / (g.tm * GW), r2 = L - ng * (g.tm * GW); mp = r2 / GW; np = ng * GW + (r2 - mp * GW); }
-      else { const int tw = g.tn - full * GW, r2 = L - nfull; mp = r2 / tw; np = full * GW + (r2 - mp * tw); }
-      m0 = mp * 256; n0 = np * 256;
-    }
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int sch = ((lane & 7) ^ ((4 * i + (lane >> 4)) & 7)) * 16;
-        oa[hf][i] = (unsigned)((long)min(m0 + 128 * hf + srow + 8 * i, g.M - 1) * g.lda_b + sch);   // < 4 GB (host-checked)
-        ob[hf][i] = (unsigned)((long)min(n0 + 128 * hf + srow + 8 * i, g.N - 1) * g.ldw_b + sch);
-      }
-  };
-  // one LDS-DMA instruction: rows 32 wave + 8 i .. + 7 of half-tile `hf` (A or B) of K-tile kt into ring slot `slot`
-  auto dma_a = [&](int hf, int i, int kt, int slot) { glds16_so(g.A + kt * 128, oa[hf][i], lds0 + slot * HT + wave * 4096u + i * 1024u); };
-  auto dma_b = [&](int hf, int i, int kt, int slot) { glds16_so(g.W + kt * 128, ob[hf][i], lds0 + slot * HT + wave * 4096u + i * 1024u); };
-  // ring: A K-tile t in slots 2 (t % 3) + {0, 1}, B K-tile t in 6 + 2 (t & 1) + {0, 1}; slots 4-5 stay free for the epilogue staging
-  auto prologue = [&]() {                           // B(0), A(0), then A(1), B(1): 32 DMA instructions per wave
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma_b(hf, i, 0, 6 + hf);
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma_a(hf, i, 0, hf);
-    if (nkt > 1) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma_a(hf, i, 1, 2 + hf);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma_b(hf, i, 1, 8 + hf);
-    }
-  };
-
-  int qi = 0;
-  int L = tile_of(0);
-  if (L < 0) return;
-  set_tile(L);
-  prologue();
-  bool stores_pending = false;
-
-  while (true) {
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // B(0), A(0) landed: younger = A(1), B(1) (16 DMA) and the previous tile's buffer stores (vmcnt counts at most 63: the wait
-    // then covers a few more of the oldest operations than strictly needed, never fewer)
-    if (stores_pending) {
-      if constexpr (NSTORE == 32) { if (nkt > 1) COR_VMCNT(48); else COR_VMCNT(32); }
-      else COR_VMCNT(63);
-    } else {
-      if (nkt > 1) COR_VMCNT(16); else COR_VMCNT(0);
-    }
-    COR_BAR();                                       // K-tile 0 visible to every wave
-
-    uint4 fa[2][4], fb[2][4];                        // fragments of the current / next k16 step
-    {
-      const char* asl = smem + wr * HT + frow;
-      const char* bsl = smem + (6 + wc) * HT + frow;
-#pragma unroll
-      for (int b4 = 0; b4 < 4; ++b4) { fa[0][b4] = *(const uint4*)(asl + b4 * 32 * 128 + chs[0]); fb[0][b4] = *(const uint4*)(bsl + b4 * 32 * 128 + chs[0]); }
-    }
-    int a3 = 0;                                      // kt % 3
-    // One K-tile. IB / IA: this K-tile issues the copies of B(kt+1) / A(kt+2); NX: a next K-tile exists (compile-time: no branch
-    // around any copy or wait inside the 64-MFMA stream; the dispatch below is one uniform branch per K-tile).
-    auto ktile = [&](int kt, auto IB_, auto IA_, auto NX_) __attribute__((always_inline)) {
-      constexpr bool IB = decltype(IB_)::value, IA = decltype(IA_)::value, NX = decltype(NX_)::value;
-      int kp = kt & 1, a3v = a3;
-      asm volatile("" : "+s"(kp), "+s"(a3v));        // opaque: keeps hipcc from hoisting slot addresses across the tile loop (gemm_pp)
-      const int a3n = a3v == 2 ? 0 : a3v + 1, a3p = a3v == 0 ? 2 : a3v - 1;
-      const char* asl = smem + (2 * a3v + wr) * HT + frow;
-      const char* bsl = smem + (6 + 2 * kp + wc) * HT + frow;
-      const char* asn = smem + (2 * a3n + wr) * HT + frow;          // K-tile kt + 1
-      const char* bsn = smem + (6 + 2 * (kp ^ 1) + wc) * HT + frow;
-      const int sa = 2 * a3p, sb = 6 + 2 * (kp ^ 1);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int cur = s4 & 1, nxt = cur ^ 1;
-        if constexpr (NX) {
-          if (s4 == 3) {
-            // K-tile kt + 1: this wave's copies of B(kt+1) (steps 0-1 of this K-tile, or the prologue) and A(kt+1) have landed;
-            // A(kt+2) half 0 (step 2) stays in flight. kt = 0: both are older than the previous tile's stores, which stay in flight too
-            if (kt == 0 && stores_pending) {
-              if constexpr (NSTORE == 32) { if constexpr (IA) COR_VMCNT(36); else COR_VMCNT(32); }
-              else COR_VMCNT(63);
-            } else { if constexpr (IA) COR_VMCNT(4); else COR_VMCNT(0); }
-            if (!COR_DBG(g, 1)) COR_BAR();
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const char* an = s4 < 3 ? asl : asn;          // where the NEXT step's fragments live
-        const char* bn = s4 < 3 ? bsl : bsn;
-        const int cn = chs[(s4 + 1) & 3];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          // next step's fragments: the step starts with row block 0 against ALL FOUR column blocks, so the B fragments are read in
-          // groups 0-1 (two MFMA groups before their first use) and the A fragments, consumed one per group, in groups 2-3
-          if (s4 < 3 || NX) {
-            if (gq < 2) { fb[nxt][2 * gq] = *(const uint4*)(bn + (2 * gq) * 32 * 128 + cn); fb[nxt][2 * gq + 1] = *(const uint4*)(bn + (2 * gq + 1) * 32 * 128 + cn); }
-            else { fa[nxt][2 * gq - 4] = *(const uint4*)(an + (2 * gq - 4) * 32 * 128 + cn); fa[nxt][2 * gq - 3] = *(const uint4*)(an + (2 * gq - 3) * 32 * 128 + cn); }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          Mfma<bf16_t>::run(fa[cur][gq], fb[cur][0], acc[gq][0]);
-          Mfma<bf16_t>::run(fa[cur][gq], fb[cur][1], acc[gq][1]);
-          __builtin_amdgcn_sched_barrier(0);
-          // one copy per group: steps 0-1 B(kt+1) halves 0-1, steps 2-3 A(kt+2) halves 0-1
-          if (s4 < 2) { if constexpr (IB) { if (!COR_DBG(g, 8)) dma_b(s4, gq, kt + 1, sb + s4); } }
-          else { if constexpr (IA) { if (!COR_DBG(g, 8)) dma_a(s4 - 2, gq, kt + 2, sa + (s4 - 2)); } }
-          __builtin_amdgcn_sched_barrier(0);
-          Mfma<bf16_t>::run(fa[cur][gq], fb[cur][2], acc[gq][2]);
-          Mfma<bf16_t>::run(fa[cur][gq], fb[cur][3], acc[gq][3]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      a3 = a3 == 2 ? 0 : a3 + 1;
-    };
-    using T_ = std::true_type; using F_ = std::false_type;
-    // nkt >= 3 (host-checked): first K-tile (B(1) came with the prologue), steady state, the last two (nothing left to copy)
-    ktile(0, F_{}, T_{}, T_{});
-    for (int kt = 1; kt < nkt - 2; ++kt) ktile(kt, T_{}, T_{}, T_{});
-    ktile(nkt - 2, T_{}, F_{}, T_{});
-    ktile(nkt - 1, F_{}, F_{}, F_{});
-
-    const int cm0 = m0, cn0 = n0;
-    const int Ln = tile_of(++qi);
-    COR_BAR();                                       // every wave is done reading the ring before the next tile's copies overwrite it
-    if (Ln >= 0) {
-      set_tile(Ln);
-      prologue();
-    }
-    float* stg = (float*)(smem + 4 * HT) + wave * 2048;     // 8 KB per wave in the free slot pair (4 KB used)
-    const int mb = cm0 + wr * WTM, nb = cn0 + wc * WTN;
-    auto fill = [&](int mi, int nj, float* st) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[mi][nj][e];
-    };
-#define COR_EPI4(A_)                                                                                            \
-    if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true, 4>(fill, stg, g, crs, mb, nb, lane);                 \
-    else epilogue_buf_ct<TO, MI, NJ, A_, false, 4>(fill, stg, g, crs, mb, nb, lane);
-    switch (g.act) {
-      case COR_ACT_GELU_ERF: COR_EPI4(COR_ACT_GELU_ERF) break;
-      case COR_ACT_RELU: COR_EPI4(COR_ACT_RELU) break;
-      case COR_ACT_SIGMOID: COR_EPI4(COR_ACT_SIGMOID) break;
-      case COR_ACT_GELU_TANH: COR_EPI4(COR_ACT_GELU_TANH) break;
-      default: COR_EPI4(COR_ACT_NONE) break;
-    }
-#undef COR_EPI4
-    if (Ln < 0) break;
-    L = Ln;
-    stores_pending = true;
-  }
-}
-
 template <typename TA, typename TO>
 __global__ void __launch_bounds__(256) gemm_nt_small(const TA* A, long lda, const TA* W, long ldw, TO* C, long ldc,
                                                      int M, int N, int K, const float* bias, int act,
@@ -1023,7 +807,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 200 && 4L * N >= 3L * 256 * cdiv(N, 256)) cfg = 13;
   }
   if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
-  if (cfg == 13 || cfg == 14 || cfg == 15) {
+  if (cfg == 13 || cfg == 14) {
     const long c_bytes = (((long)M - 1) * ldc + N) * (long)sizeof(TO);
     const bool ok = sizeof(TA) == 2 && k128 && g.vec_epi && !col_scale && N % 8 == 0 && c_bytes < (1L << 32) - 64 &&
                     (long)M * g.lda_b < (1L << 32) && (long)N * g.ldw_b < (1L << 32);   // 32-bit operand offsets
@@ -1047,14 +831,6 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
       const int total = g.tm * g.tn;
       int blocks = n_cu - (n_cu & 7);
       if (total < blocks) blocks = ((total + 7) / 8) * 8;
-      if (cfg == 15 && g.Kb / 128 < 3) cfg = 13;    // the one-wave-per-SIMD kernel peels three K-tiles
-      if (cfg == 15) {
-        static DevOnce once_w4;
-        cor_max_dyn_lds((const void*)gemm_w4<TO>, 163840, once_w4);
-        hipLaunchKernelGGL((gemm_w4<TO>), dim3(blocks), dim3(256), 163840, s, g);
-        COR_CHECK_LAUNCH();
-        return 0;
-      }
 #ifdef COR_PROBES
       if (cfg == 14) hipLaunchKernelGGL((gemm_pp<TO, true>), dim3(blocks), dim3(512), 163840, s, g);
       else
@@ -1083,10 +859,10 @@ extern "C" int cor_gemm(const void* A, long lda, const void* W, long ldw, int ab
   {
     const int sel = cfg & 0xff;
 #ifdef COR_PROBES
-    if (cfg < 0 || sel > 15) return COR_EINVAL;
+    if (cfg < 0 || sel > 14) return COR_EINVAL;
 #else
     // production: automatic or one of the shipped kernels, optionally | COR_ORDER_REVERSE; no ablation bits, no 16x16 probe kernel
-    if (cfg < 0 || (cfg & ~(0xff | COR_ORDER_REVERSE)) != 0 || !(sel == 0 || sel == 1 || sel == 2 || sel == 3 || sel == 4 || sel == 9 || sel == 13 || sel == 15)) return COR_EINVAL;
+    if (cfg < 0 || (cfg & ~(0xff | COR_ORDER_REVERSE)) != 0 || !(sel == 0 || sel == 1 || sel == 2 || sel == 3 || sel == 4 || sel == 9 || sel == 13)) return COR_EINVAL;
 #endif
   }
   if (residual && ldr < N) return COR_EINVAL;
