@@ -81,6 +81,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if this library were resolved first it would bind the
+    # system copy under /opt/rocm and the kernels would launch into a runtime torch never initialised (hipErrorNoDevice at the first
+    # launch: seen when __graft_entry__.build() and smoke() ran in one process). Importing torch first makes both use torch's copy.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"cor_amd: HIP extension not built ({LIB_PATH} missing). There is no CPU fallback. "
