@@ -46,6 +46,7 @@ struct GemmArgs {
   int dbg;             // timing-only ablation knobs (tools/gemm_ksweep.py): 1 no C stores, 2 no epilogue, 4 no MFMA
   int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
   int rev;             // 1: walk the tile order backwards (COR_ORDER_REVERSE: start where the producer of A finished)
+  int nt_c;            // persistent kernel: 1 = non-temporal C stores
   int order;           // persistent kernel: 1 = XCD-stationary W-panels (default), 0 = round-2 banded order (COR_PROBES A/B: cfg bit 20)
 };
 
@@ -381,7 +382,10 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
       const int m = min(mbase + mi * 32 + ps * RPP + row0, g.M - 1);
       const int rr = g.res_row_mod > 0 ? m % g.res_row_mod : m;
 #pragma unroll
-      for (int q4 = 0; q4 < Q4; ++q4) r[ps][q4] = *(const f32x4*)(g.residual + (long)rr * g.ldr + min(n + 4 * q4, g.N - 4));
+      for (int q4 = 0; q4 < Q4; ++q4) {
+        const f32x4* rp = (const f32x4*)(g.residual + (long)rr * g.ldr + min(n + 4 * q4, g.N - 4));
+        r[ps][q4] = COR_DBG(g, 0x8000) ? __builtin_nontemporal_load(rp) : *rp;           // probe: non-temporal residual loads
+      }
     }
   };
   if constexpr (HAS_RES) {
@@ -417,7 +421,9 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
       } else {
         u[0] = __float_as_uint(v[0][0]); u[1] = __float_as_uint(v[0][1]); u[2] = __float_as_uint(v[0][2]); u[3] = __float_as_uint(v[0][3]);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
+      if (g.nt_c || COR_DBG(g, 0x2000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);   // non-temporal C stores (see launch_gemm)
+      else if (COR_DBG(g, 0x4000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 16);       // probe: sc1 (dropped from L2) C stores
+      else __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
     }
     if constexpr (HAS_RES) {
       if (blk + D < NB) load_res(blk + D, res[blk % D]);
@@ -789,8 +795,13 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
   g.M = M; g.N = N; g.Kb = (int)(K * esz);
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
-  g.dbg = g_gemm_dbg & 0xfff; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
+  g.dbg = g_gemm_dbg & 0xefff; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
   g.order = 1;                                       // resolved below (persistent kernel only): see set_tile
+  // bf16 outputs larger than the 256-MiB Infinity Cache (qkv, MLP hidden at batch 32) are stored non-temporally: they cannot stay
+  // on-die until their consumer runs anyway, and as plain stores they evict the A / W panels the K loops re-read from L2
+  // (tools/gemm_store_policy_ab.py: qkv 464 -> 436 us, lin1+GELU 685 -> 644 us, fp32 residual outputs unchanged, sc1 stores slower;
+  // +0.5 ... 1 % on the bench step, where the consumers lose their Infinity-Cache hits on the tail of these tensors)
+  g.nt_c = (sizeof(TO) == 2 && !residual && (long)M * N * 2 >= (256L << 20)) ? 1 : 0;
   g.group_m = ((g_gemm_dbg >> 4) & 0xff) ? ((g_gemm_dbg >> 4) & 0xff) : 8;
   const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   g.vec_epi = (N % 4 == 0) && (N >= 8) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
