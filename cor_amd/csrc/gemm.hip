@@ -363,12 +363,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   typedef float f32x2_v __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_v){a, b}, bf16x2_v));   // one v_cvt_pk_bf16_f32
 }
-template <typename TO, int MI, int NJ, int ACT, bool HAS_RES, typename FILL>
-__device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const GemmArgs& g, __amdgpu_buffer_rsrc_t crs,
+template <typename TO, int MI, int NJ, int ACT, bool HAS_RES, bool NT, typename FILL, typename PRE, typename BCOL>
+__device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, PRE&& pre, BCOL&& bias_col, float* stg, const GemmArgs& g, __amdgpu_buffer_rsrc_t crs,
                                                 int mbase, int nbase, int lane) {
   constexpr int VW = sizeof(TO) == 2 ? 8 : 4;
   constexpr int CV = 32 / VW, RPP = 64 / CV, PASS = 32 / RPP, Q4 = VW / 4;   // bf16: 4 lanes/row, 16 rows/pass, 2 passes
-  constexpr int NB = MI * NJ, D = (HAS_RES && sizeof(TO) == 4) ? 2 : 1;       // residual prefetch depth (4, or 2 with bf16 C: spills into the K loop)
+  constexpr bool HEAVY_ACT = ACT != COR_ACT_NONE && ACT != COR_ACT_RELU;             // exp + rcp temporaries: depth 2 spills 5-6 registers there
+  constexpr int NB = MI * NJ, D = (HAS_RES && sizeof(TO) == 4 && !HEAVY_ACT) ? 2 : 1;   // residual prefetch depth (deeper, or 2 with bf16 C: spills)
   const int cv = lane % CV, row0 = lane / CV;
   // Residual loads run D blocks ahead of their use (the K-loop fragment registers are free here): one block at a time, each
   // block waited for its own HBM round trip and - VMEM retiring in order - for the previous block's stores, eight times per
@@ -388,18 +389,31 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
       }
     }
   };
+  // The bias is loaded ONCE per tile, before the next tile's LDS-DMAs (`pre`) and before any store of this tile, in ACCUMULATOR
+  // layout (a lane of the MFMA C layout owns one column per 32-column block: NJ registers) and added while the block is written
+  // to the staging buffer. VMEM retires in order and hipcc waits with vmcnt(#its own younger operations): a bias load issued
+  // inside the block loop (rounds 1-2) was waited for with vmcnt(0), which drained the previous block's stores, the residual
+  // prefetch and the next tile's sixteen LDS-DMAs eight times per tile. Without a residual the epilogue now contains no wait on
+  // vector memory at all: the stores stream out under the next tile's K loop.
+  float bcol[NJ][2];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) bcol[nj][jb] = g.bias ? g.bias[min(nbase + bias_col(nj, jb), g.N - 1)] : 0.0f;
   if constexpr (HAS_RES) {
 #pragma unroll
     for (int d = 0; d < D; ++d) load_res(d, res[d]);
   }
 #pragma unroll
+  for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+v"(bcol[nj][jb]));   // hipcc places the bias wait HERE (nothing younger but the residual prefetch)
+  pre();                                              // next tile: operand offsets + prologue LDS-DMAs (not tracked by hipcc)
+#pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int mi = blk / NJ, nj = blk % NJ;
     const int n = nbase + nj * 32 + cv * VW;
-    f32x4 bv[Q4];                                     // bias reloaded per block (L1 hit): 16 fewer live registers than hoisted
-#pragma unroll
-    for (int q4 = 0; q4 < Q4; ++q4) bv[q4] = g.bias ? *(const f32x4*)(g.bias + min(n + 4 * q4, g.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    fill(mi, nj, stg);                                // the wave's 32x32 block (mi, nj) -> stg[32][32]
+    fill(mi, nj, stg, bcol[nj]);                      // the wave's 32x32 block (mi, nj) + bias -> stg[32][32]
 #pragma unroll
     for (int ps = 0; ps < PASS; ++ps) {
       const int row = ps * RPP + row0;
@@ -407,7 +421,7 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
       f32x4 v[Q4];
 #pragma unroll
       for (int q4 = 0; q4 < Q4; ++q4) {
-        v[q4] = *(const f32x4*)(stg + row * 32 + cv * VW + 4 * q4) + bv[q4];
+        v[q4] = *(const f32x4*)(stg + row * 32 + cv * VW + 4 * q4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q4][q] = act_ct<ACT, TO>(v[q4][q]);
         if constexpr (HAS_RES) v[q4] += res[blk % D][ps][q4];
@@ -421,8 +435,10 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, float* stg, const G
       } else {
         u[0] = __float_as_uint(v[0][0]); u[1] = __float_as_uint(v[0][1]); u[2] = __float_as_uint(v[0][2]); u[3] = __float_as_uint(v[0][3]);
       }
-      if (g.nt_c || COR_DBG(g, 0x2000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);   // non-temporal C stores (see launch_gemm)
-      else if (COR_DBG(g, 0x4000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 16);       // probe: sc1 (dropped from L2) C stores
+      // NT (compile-time: a runtime choice of the cache-policy immediate was three branches per store): non-temporal C stores, see launch_gemm
+      if constexpr (NT) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);
+      else if (COR_DBG(g, 0x2000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);        // probes: nt / sc1 on any output
+      else if (COR_DBG(g, 0x4000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 16);
       else __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
     }
     if constexpr (HAS_RES) {
@@ -673,29 +689,35 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 
     const int cm0 = m0, cn0 = n0;
     const int Ln = tile_of(++qi);
-    if (Ln >= 0) {
-      set_tile(Ln);
-      prologue();
-    }
+    auto pre = [&]() {                               // runs inside the epilogue, after its first loads (see epilogue_buf_ct)
+      if (Ln >= 0) {
+        set_tile(Ln);
+        prologue();
+      }
+    };
     float* stg = (float*)(smem + 4 * HT) + wave * 1024;
     const int mb = cm0 + wr * WTM, nb = cn0 + wc * WTN;
-    auto fill = [&](int mi, int nj, float* st) {    // MFMA C layouts: 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5);
+    // column (inside the wave's 64) of the bias a lane adds to block nj: 32x32: col = lane&31; 16x16: the two 16-column halves jb
+    auto bias_col = [&](int nj, int jb) -> int { return M16 ? nj * 32 + jb * 16 + r : nj * 32 + r; };
+    auto fill = [&](int mi, int nj, float* st, const float (&b)[2]) {   // MFMA C layouts: 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5);
       if constexpr (M16) {                           // 16x16: col = lane&15, row = 4*(lane>>4) + e
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[(ib * 16 + q * 4 + e) * 32 + jb * 16 + r] = acc16[2 * mi + ib][2 * nj + jb][e];
+            for (int e = 0; e < 4; ++e) st[(ib * 16 + q * 4 + e) * 32 + jb * 16 + r] = acc16[2 * mi + ib][2 * nj + jb][e] + b[jb];
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[mi][nj][e];
+        for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[mi][nj][e] + b[0];
       }
     };
 #define COR_EPI(A_)                                                                                             \
-    if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true>(fill, stg, g, crs, mb, nb, lane);                   \
-    else epilogue_buf_ct<TO, MI, NJ, A_, false>(fill, stg, g, crs, mb, nb, lane);
+    if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane);          \
+    else if (sizeof(TO) == 2 && g.nt_c) epilogue_buf_ct<TO, MI, NJ, A_, false, sizeof(TO) == 2>(fill, pre, bias_col, stg, g, crs, mb, nb, lane); \
+    else epilogue_buf_ct<TO, MI, NJ, A_, false, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane);
     if (COR_DBG(g, 2)) {                             // timing ablation: one element per lane instead of the epilogue
+      pre();
       float t = 0.f;
       if constexpr (M16) {
 #pragma unroll

@@ -6,9 +6,9 @@ sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops, _native as _nat
 _nat.use_probe_library()        # ablation knobs (bits 8.. of cfg) exist in the COR_PROBES build only: make -C cor_amd/csrc probes, _native
-lib = _native.load(); dev = "cuda:0"; T = torch.bfloat16
+lib = _nat.load(); dev = "cuda:0"; T = torch.bfloat16
 cfgs = [int(c) for c in sys.argv[1:]] or [2, 3]   # 7xx = persistent kernel with ablation knob xx (1 no stores, 2 no epilogue, 4 no MFMA)
-M, N = 131072, 768
+M, N = 131072, int(os.environ.get("KSWEEP_N", "768"))
 for mode in ("bf16_out", "bf16_out_gelu", "f32_out_res"):
     for K in (64, 768, 3072):
         A = torch.randn((M, K), device=dev).to(T); W = (torch.randn((N, K), device=dev) / K ** 0.5).to(T)
