@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""gemm_fr (cfg 15, free-running 8-wave form) against gemm_pp (cfg 13): bit equality on block shapes + ragged edges, then timing."""
+"""gemm_fr (cfg 15, free-running 8-wave form) against gemm_pp (cfg 13): bit equality on block shapes + ragged edges, then timing.
+Needs profiles/r03_gemm_free_running_negative.patch applied (the shipped library answers cfg 15 with COR_EINVAL): the kernel was
+measured slower and is kept as a patch + this checker only."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
