@@ -447,6 +447,65 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, PRE&& pre, BCOL&& b
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 epilogue of the persistent kernel on C^T accumulators (operands exchanged in the K loop): lane (m = lane&31, h = lane>>5) owns
+// row m of a 32x32 block and its columns 8g + 4h + i (g, i = 0..3): four runs of four consecutive columns. Per block ROW (mi) the wave
+// adds the bias, applies the activation, rounds to bf16 and writes 4 x 8 bytes per block into its 4-KB staging slot laid out as
+// [32 rows][64 columns] bf16 = 128-byte rows (16-byte chunk c stored at c ^ ((m>>1)&7): conflict-free ds_write_b64 and ds_read_b128),
+// then reads it back as 4 x (8 rows x 128 B) and stores WHOLE 128-byte lines: 8 lanes x 16 B per row (the fp32-staged epilogue wrote
+// 64-byte half lines from different instructions: WRITE_SIZE 1.32x the size of C, and 2.4x the LDS instructions). Same 16 buffer stores
+// per wave and tile. The bias of the lane's 32 columns is loaded once per tile, before the next tile's LDS-DMAs (see epilogue_buf_ct).
+// No residual (the host routes bf16 C + residual to the 128x128 kernel).
+template <int MI, int NJ, int ACT, bool NT, typename ACCV, typename PRE>
+__device__ __forceinline__ void epilogue_ct16(ACCV&& accv, PRE&& pre, char* stg, const GemmArgs& g, __amdgpu_buffer_rsrc_t crs,
+                                              int mbase, int nbase, int lane) {
+  static_assert(NJ == 2, "a wave's 64 columns = one 128-byte row of bf16");
+  const int mrow = lane & 31, h = lane >> 5;
+  f32x4 bd[NJ][4];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      bd[nj][gq] = g.bias ? *(const f32x4*)(g.bias + min(nbase + nj * 32 + 8 * gq + 4 * h, g.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) asm volatile("" : "+v"(bd[nj][gq]));   // hipcc places the bias wait HERE, before the LDS-DMAs it does not count
+  pre();
+  const int wsw = (mrow >> 1) & 7;
+  char* wrow = stg + mrow * 128 + h * 8;
+  const int rr0 = lane >> 3, cvr = lane & 7;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = act_ct<ACT, bf16_t>(accv(mi, nj, 4 * gq + i) + bd[nj][gq][i]);
+        uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+        *(uint2*)(wrow + (((nj * 4 + gq) ^ wsw) << 4)) = u;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      const int row = p4 * 8 + rr0;
+      const uint4 q = *(const uint4*)(stg + row * 128 + ((cvr ^ ((row >> 1) & 7)) << 4));
+      const int m = mbase + mi * 32 + row, n = nbase + cvr * 8;
+      const unsigned off = (m < g.M && n < g.N) ? (unsigned)(((long)m * g.ldc + n) * 2L) : 0xFFFFFFFFu;
+      u32x4 u; u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
+      if constexpr (NT) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);
+      else if (COR_DBG(g, 0x2000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);
+      else if (COR_DBG(g, 0x4000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 16);
+      else __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slot is rewritten by the next block row
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 #define COR_VMCNT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -482,6 +541,10 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
   constexpr int VW = sizeof(TO) == 2 ? 8 : 4;
   constexpr int NSTORE = MI * NJ * (32 / (64 / (32 / VW)));          // buffer stores per wave per tile: 16 (bf16) / 32 (fp32)
   static_assert(NSTORE == 16 || NSTORE == 32, "counted waits below");
+  // bf16 C: the MFMA operands are exchanged (A operand = W rows), so an accumulator block holds C^T - a lane owns ONE row m of the block
+  // and 16 of its columns in runs of four - and the epilogue stages bf16 rows of the wave's whole 64 columns: whole 128-byte lines per
+  // store instruction (epilogue_ct16). The products and their order per k16 step are the same: bit-identical results.
+  constexpr bool CT = sizeof(TO) == 2 && !M16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -641,7 +704,10 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { Mfma<bf16_t>::run(af[i][s4], bf[0][s4], acc[i][0]); Mfma<bf16_t>::run(af[i][s4], bf[1][s4], acc[i][1]); }
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (CT) { Mfma<bf16_t>::run(bf[0][s4], af[i][s4], acc[i][0]); Mfma<bf16_t>::run(bf[1][s4], af[i][s4], acc[i][1]); }
+            else              { Mfma<bf16_t>::run(af[i][s4], bf[0][s4], acc[i][0]); Mfma<bf16_t>::run(af[i][s4], bf[1][s4], acc[i][1]); }
+          }
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -678,7 +744,10 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { Mfma<bf16_t>::run(af[i][s4], bf[0][s4], acc[2 + i][0]); Mfma<bf16_t>::run(af[i][s4], bf[1][s4], acc[2 + i][1]); }
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (CT) { Mfma<bf16_t>::run(bf[0][s4], af[i][s4], acc[2 + i][0]); Mfma<bf16_t>::run(bf[1][s4], af[i][s4], acc[2 + i][1]); }
+            else              { Mfma<bf16_t>::run(af[i][s4], bf[0][s4], acc[2 + i][0]); Mfma<bf16_t>::run(af[i][s4], bf[1][s4], acc[2 + i][1]); }
+          }
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -712,7 +781,12 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
         for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[mi][nj][e] + b[0];
       }
     };
+    auto accv = [&](int mi, int nj, int e) -> float { if constexpr (M16) return 0.0f; else return acc[mi][nj][e]; };
 #define COR_EPI(A_)                                                                                             \
+    if constexpr (CT) {                                                                                         \
+      if (g.nt_c) epilogue_ct16<MI, NJ, A_, true>(accv, pre, (char*)stg, g, crs, mb, nb, lane);                \
+      else epilogue_ct16<MI, NJ, A_, false>(accv, pre, (char*)stg, g, crs, mb, nb, lane);                      \
+    } else                                                                                                      \
     if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane);          \
     else if (sizeof(TO) == 2 && g.nt_c) epilogue_buf_ct<TO, MI, NJ, A_, false, sizeof(TO) == 2>(fill, pre, bias_col, stg, g, crs, mb, nb, lane); \
     else epilogue_buf_ct<TO, MI, NJ, A_, false, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane);
@@ -842,7 +916,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
   if (cfg == 13 || cfg == 14) {
     const long c_bytes = (((long)M - 1) * ldc + N) * (long)sizeof(TO);
-    const bool ok = sizeof(TA) == 2 && k128 && g.vec_epi && !col_scale && N % 8 == 0 && c_bytes < (1L << 32) - 64 &&
+    const bool ok = sizeof(TA) == 2 && k128 && g.vec_epi && !col_scale && N % 8 == 0 && c_bytes < (1L << 32) - 64 && !(sizeof(TO) == 2 && residual) &&
                     (long)M * g.lda_b < (1L << 32) && (long)N * g.ldw_b < (1L << 32);   // 32-bit operand offsets
     if (!ok) cfg = k128 ? 2 : 1;
     else if constexpr (sizeof(TA) == 2) {
