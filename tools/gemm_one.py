@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops, _native
-if len(sys.argv) > 4 and int(sys.argv[4]) >> 8:      # ablation / order bits: only the COR_PROBES build accepts them
+if len(sys.argv) > 4 and (int(sys.argv[4]) >> 8 or (int(sys.argv[4]) & 0xff) == 14):      # ablation / order bits, 16x16-MFMA form: only the COR_PROBES build accepts them
     _native.use_probe_library()
 M, N, K = (int(v) for v in sys.argv[1:4]); cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 mode = sys.argv[5] if len(sys.argv) > 5 else "plain"
