@@ -893,11 +893,12 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
   g.dbg = g_gemm_dbg & 0xefff; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
   g.order = 1;                                       // resolved below (persistent kernel only): see set_tile
-  // bf16 outputs larger than the 256-MiB Infinity Cache (qkv, MLP hidden at batch 32) are stored non-temporally: they cannot stay
-  // on-die until their consumer runs anyway, and as plain stores they evict the A / W panels the K loops re-read from L2
-  // (tools/gemm_store_policy_ab.py: qkv 464 -> 436 us, lin1+GELU 685 -> 644 us, fp32 residual outputs unchanged, sc1 stores slower;
-  // +0.5 ... 1 % on the bench step, where the consumers lose their Infinity-Cache hits on the tail of these tensors)
-  g.nt_c = (sizeof(TO) == 2 && !residual && (long)M * N * 2 >= (256L << 20)) ? 1 : 0;
+  // bf16 outputs of the persistent kernel are stored non-temporally: with the whole-line epilogue every store instruction writes
+  // complete 128-byte lines, nothing is left for a cache to merge, and as plain stores the C stream evicts the A / W panels the K
+  // loops re-read from L2 (tools/gemm_store_policy_ab.py: qkv 464 -> 436 us, lin1+GELU 685 -> 644 us on the box where it mattered;
+  // bench A/B of the final build, two alternating rounds: no nt 711 / 712, nt for outputs >= 256 MiB 713 / 720, nt for all 724 / 726
+  // triplets/s). fp32 residual outputs keep the default policy (the next LayerNorm re-reads them out of the Infinity Cache).
+  g.nt_c = (sizeof(TO) == 2 && !residual) ? 1 : 0;
   g.group_m = ((g_gemm_dbg >> 4) & 0xff) ? ((g_gemm_dbg >> 4) & 0xff) : 8;
   const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   g.vec_epi = (N % 4 == 0) && (N >= 8) && (ldc % (sizeof(TO) == 2 ? 8 : 4) == 0) && al16(C) && (!bias || al16(bias)) && (!col_scale || al16(col_scale)) &&
