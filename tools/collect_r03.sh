@@ -1,13 +1,13 @@
 #!/bin/bash
 # Copy the summaries of tools/measure_r03.sh (gpurun_out/m3, scratch) into profiles/ (tracked).
 O=gpurun_out/m3; P=profiles
-find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $P/r03_kernel_stats.csv
+ls -t $(find $O/prof_bench -name "*kernel_stats.csv") | head -1 | xargs -I{} cp {} $P/r03_kernel_stats.csv   # newest: gpurun_out/ keeps the files of earlier passes
 grep '^{"metric"' $O/prof_bench.json > $P/r03_kernel_stats_bench_line.json
 grep '^{"metric"' $O/bench.json > $P/r03_bench.json
 cp $O/pmc_traffic.json $P/r03_pmc_traffic.json
 cp $O/sim_pmc_traffic.json $P/r03_similarity_pmc_traffic.json
 cp $O/sim_bench.jsonl $P/r03_similarity_bench.jsonl
-find $O/prof_sim -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $P/r03_similarity_kernel_stats.csv
+ls -t $(find $O/prof_sim -name "*kernel_stats.csv") | head -1 | xargs -I{} cp {} $P/r03_similarity_kernel_stats.csv
 cp $O/attn_bench.jsonl $P/r03_attention_bench.jsonl
 cp $O/gemm_shapes.jsonl $P/r03_gemm_shapes.jsonl
 for c in L f32 host eager; do grep '^{"metric"' $O/bench_$c.json > $P/r03_bench_$c.json; done
