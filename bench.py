@@ -2,7 +2,15 @@
 """bench.py — CORE retrieval-time forward on MI355X: query triplets/sec (forward + gallery similarity + top-k).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...          # no WORLD_SIZE in the environment: this process starts the N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Launching. `--gpus N` is honoured in every form: with WORLD_SIZE unset and N > 1 this process - which has
+imported nothing that touches the GPU - starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free port> bench.py <same arguments>` as a CHILD, relays its output (rank 0's JSON line) and exits with its code;
+with WORLD_SIZE set (the driver's torchrun form) it must equal --gpus, else the run refuses (exit 2) instead of printing N copies
+of a 1-GPU number. The N > 1 line carries `rccl`: the backend and world size torch.distributed reports, and the mean
+`collective_ms` (query all-gather + list gather) and `search_ms` of the steps, so that the scaling curve can be decomposed.
 
 Workload (BASELINE.json metric: "query triplets/sec + Recall@1 vs 100k-region gallery"; model/batch of configs[1]):
 SAM-ViT-B + SigLIP-B/16-384 + MaskAdapterPooling, batch 32 triplets per GPU, bf16 fast mode, synthetic inputs /
@@ -27,10 +35,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+# torch is imported in main(), AFTER the launch decision: the launching parent stays free of any GPU runtime.
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -51,8 +59,84 @@ def parse():
                     "steps right after the timed region. 0: eager launches, events inside the timed region")
     ap.add_argument("--host-inputs", type=int, default=0, help="1: the batch starts in pinned host memory and is copied H2D inside every step "
                     "on a second stream, double-buffered (PCIe-inclusive rate for DESIGN.md; never the headline value)")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
+    ap.add_argument("--multimask", type=int, default=1, help="multimask_output of the forward (1: three masks + IoU arg-max select, as in rounds 1-3; "
+                    "0: the reference's shipped config/vaild_config/vaild_config.yaml:13 - skips cor_iou_select's 3-way arg-max)")
+    ap.add_argument("--launch-check", action="store_true", help="rehearse the launch path only: every rank joins the process group (gloo: no GPU "
+                    "needed), all-reduces its rank and rank 0 prints one JSON line; nothing is benchmarked (tests/test_cpu_host.py)")
+    return ap.parse_args(argv)
+
+
+def launch_plan(gpus: int, env) -> tuple:
+    """What this invocation must do, from --gpus and the environment alone (no GPU, no torch): ("run", None) - this process is a
+    rank (or the single process of N = 1); ("spawn", N) - start N ranks as children; ("refuse", message) - WORLD_SIZE and --gpus
+    disagree (a SCALE run must never print N copies of the 1-GPU number)."""
+    if gpus < 1:
+        return "refuse", f"--gpus {gpus}: need at least one GPU"
+    ws = env.get("WORLD_SIZE")
+    if ws is None:
+        return ("run", None) if gpus == 1 else ("spawn", gpus)
+    try:
+        ws = int(ws)
+    except ValueError:
+        return "refuse", f"WORLD_SIZE={ws!r} is not an integer"
+    if ws != gpus:
+        return "refuse", f"WORLD_SIZE={ws} but --gpus {gpus}: launch one rank per GPU (or drop WORLD_SIZE and let bench.py start them)"
+    return "run", None
+
+
+def spawn_command(n: int, argv, port: int) -> list:
+    """The child command of the ("spawn", N) plan: the driver's own torchrun form with this script's arguments unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Start the N ranks as ONE child (torchrun), relay its stdout line by line (rank 0's JSON line is the only line the ranks
+    print there), return its exit code. The parent never initialises a GPU runtime, so no exec / fork hazard arises."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0))) // n)))
+    proc = subprocess.Popen(spawn_command(n, argv, port), stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    got_line = False
+    for line in proc.stdout:
+        got_line = got_line or line.startswith("{")
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print("bench.py: the ranks exited 0 without printing a result line", file=sys.stderr)
+        return 3
+    return rc
+
+
+def launch_check(args):
+    """--launch-check: the rank side of the launch path without the benchmark (CPU-only under gloo)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    total = rank
+    if world > 1:
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+            t = torch.tensor([rank], dtype=torch.int64)
+        else:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            t = torch.tensor([rank], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        total, got_world, backend = int(t.item()), dist.get_world_size(), dist.get_backend()
+        dist.destroy_process_group()
+    else:
+        got_world, backend = 1, "none"
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "gpus": args.gpus, "world_size": got_world, "backend": backend, "rank_sum": total}), flush=True)
 
 
 NB_CPU = 3          # bounded CPU sample: 3 triplets ~ 14 s on 16 cores (the contract asks for 10-30 s)
@@ -76,8 +160,10 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
     the first NB_CPU queries, the fp32 CPU oracle itself. Positives are planted from the reference features
     (gallery[pi(b)] = normalize(q_b + 0.1 N(0,1))); the benchmarked pipeline (feat_fast: the bf16 forward's features, then
     cor_similarity_topk on the bf16 gallery) must return the reference's top-1 (fp32 features, fp32 CPU product on the same rows)."""
+    import torch
     from oracle import model as omodel, retrieval as oret
     from cor_amd import retrieval
+    mm = bool(args.multimask)
     ncores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box gives one GPU's share of the host: 16 cores
     torch.set_num_threads(ncores)
     sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
@@ -86,7 +172,7 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
     t0 = time.perf_counter()
     with torch.no_grad():
         _, _, feat = omodel.forward(sd, args.sam, args.siglip, "MaskAdapterPooling", inp["query_image_inputs"], inp["support_image_inputs"],
-                                    inp["change_text_inputs"], inp["support_mask_inputs"], True)
+                                    inp["change_text_inputs"], inp["support_mask_inputs"], mm)
         oret.similarity_topk(feat[:, 0], G32, args.topk)
     dt = time.perf_counter() - t0
     cpu = dict(value=NB_CPU / dt, unit="triplets/s", cores=torch.get_num_threads(), kind="port",
@@ -98,18 +184,27 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
     fast_dtype = model.compute_dtype
     model.compute_dtype = torch.float32
     with torch.no_grad():
-        q_ref = torch.cat([model(**{k: v[i:i + 8] for k, v in batch.items()}, multimask_output=True)[2][:, 0] for i in range(0, B, 8)]).float().cpu()
+        q_ref = torch.cat([model(**{k: v[i:i + 8] for k, v in batch.items()}, multimask_output=mm)[2][:, 0] for i in range(0, B, 8)]).float().cpu()
     model.compute_dtype = fast_dtype
     cosm = q_ref.double() @ q_ref.double().T - 2 * torch.eye(B, dtype=torch.float64)
     gen = torch.Generator(device="cpu").manual_seed(4321)
-    where = torch.arange(B) * 2999 + 13                                              # < 100000 for B <= 33
+    Gn = gallery_rows_cpu.shape[0]
+    if Gn < 14 + B:
+        raise ValueError(f"recall leg: a {Gn}-row gallery cannot hold {B} planted positives")
+    where = 13 + torch.arange(B) * ((Gn - 14) // max(B, 1))                          # distinct, < Gn for every batch / gallery size
+    assert int(where.max()) < Gn and where.unique().numel() == B
     G = gallery_rows_cpu.clone()
     G[where] = torch.nn.functional.normalize(q_ref + 0.1 * torch.randn(q_ref.shape, generator=gen), dim=-1)
     G = G.to(torch.bfloat16)
     rs, ri = oret.similarity_topk(q_ref, G.float(), args.topk)                       # fp32 reference features, fp32 CPU product
     _, ri_cpu = oret.similarity_topk(q_cpu, G.float(), args.topk)                    # fp32 CPU oracle end to end (first NB_CPU queries)
-    gs, gi = retrieval.GalleryShard(G.to(dev), 0).search(feat_fast.float().contiguous(), args.topk)
+    gshard = retrieval.GalleryShard(G.to(dev), 0)
+    gs, gi = gshard.search(feat_fast.float().contiguous(), args.topk)
     gi = gi.cpu()
+    # north_star's "bit-exact top-k indices" claim, end to end in the mode that can deliver it: exact-fp32 HIP forward +
+    # cor_similarity_topk on the device  vs  fp32 CPU oracle forward + CPU chain top-k, same weights / inputs / gallery
+    _, gi32 = gshard.search(q_ref[:NB_CPU].to(dev).contiguous(), args.topk)
+    gi32 = gi32.cpu()
     rec = dict(recall_at_1=float((gi[:, 0] == ri[:, 0]).float().mean()), queries=B,
                recall_at_1_planted=float((gi[:, 0] == where).float().mean()), oracle_recall_at_1_planted=float((ri[:, 0] == where).float().mean()),
                topk_index_mismatches=int((gi != ri).sum()), topk_entries=int(ri.numel()),
@@ -117,15 +212,40 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
                cpu_oracle_queries=NB_CPU, cpu_oracle_recall_at_1=float((gi[:NB_CPU, 0] == ri_cpu[:, 0]).float().mean()),
                cpu_oracle_recall_at_1_planted=float((ri_cpu[:, 0] == where[:NB_CPU]).float().mean()),
                cpu_oracle_vs_fp32_hip_feature_max_abs_err=float((q_cpu - q_ref[:NB_CPU]).abs().max()),
+               fp32_mode_topk_index_mismatches_vs_cpu_oracle=int((gi32 != ri_cpu).sum()), fp32_mode_topk_entries=int(ri_cpu.numel()),
+               fp32_mode_features_cpu_topk_index_mismatches_vs_cpu_oracle=int((ri[:NB_CPU] != ri_cpu).sum()),
                definition="top-1 of the benchmarked pipeline (bf16 forward + cor_similarity_topk, bf16 gallery) == top-1 of the reference (exact-fp32 HIP "
                           "features, pinned to the reference's goldens; fp32 CPU product) over all queries, gallery with one planted positive per query; "
-                          "cpu_oracle_*: the same against the fp32 CPU oracle's own features for the first queries; inputs: per-sample texture tiles, "
+                          "cpu_oracle_*: the same against the fp32 CPU oracle's own features for the first queries; fp32_mode_topk_index_mismatches_vs_cpu_oracle: "
+                          "top-k INDICES of the exact-fp32 HIP pipeline end to end (fp32 forward + cor_similarity_topk) vs the fp32 CPU oracle end to end (its own "
+                          "forward + chain top-k) on the first queries - north_star's bit-exact top-k claim in the mode that can deliver it (the exact-fp32 HIP mode "
+                          "is pinned to the reference's goldens by tests/test_gpu_parity.py::test_batch32_bf16_vs_fp32_exact_mode_anchored_to_the_golden); inputs: per-sample texture tiles, "
                           "support-head biases zeroed (utils.synthetic_batch(structured=True), utils.zero_support_head_biases: de-collinearised queries)")
     return cpu, rec
 
 
+def stated_cpu_baseline():
+    """SURVEY 8d's stated CPU protocol (configs[0]: raw 224x224 images resized first, B = 1 and 4, 1k gallery, 1 warm-up + 3 timed),
+    recorded once by tools/cpu_baseline.py on a GPU box's host cores; quoted beside the bounded sample when the file exists."""
+    f = os.path.join(ROOT, "profiles", "r04_cpu_baseline.json")
+    try:
+        j = json.load(open(f))
+        return dict(file=os.path.relpath(f, ROOT), **{k: j[k] for k in ("B1", "B4", "cores", "threads", "protocol") if k in j})
+    except Exception:                                    # noqa: BLE001
+        return None
+
+
 def main():
     args = parse()
+    plan, detail = launch_plan(args.gpus, os.environ)
+    if plan == "refuse":
+        print(f"bench.py: {detail}", file=sys.stderr)
+        raise SystemExit(2)
+    if plan == "spawn":
+        raise SystemExit(spawn_ranks(detail, sys.argv[1:]))
+    if args.launch_check:
+        return launch_check(args)
+    import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -133,6 +253,9 @@ def main():
         raise SystemExit("bench.py needs a GPU; the HIP path has no CPU fallback")
     if args.backend == "gloo":
         local_rank = 0                                   # rehearsal: all ranks share the one visible GPU
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} over RCCL needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         "(--backend gloo rehearses several ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -143,6 +266,7 @@ def main():
     from cor_amd.lib.build_model import build_model_with_query_support_feat
 
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    mm = bool(args.multimask)
     model = build_model_with_query_support_feat(args.sam, args.siglip, None, None, "MaskAdapterPooling")
     utils.randomize_parameters(model, seed=0)
     utils.zero_support_head_biases(model)               # with structured inputs: 32 distinct query embeddings instead of 32 collinear ones
@@ -164,7 +288,7 @@ def main():
     graphed, launch_mode = None, "eager ctypes launches"     # (captured BEFORE the process group exists: no RCCL host threads beside the capture)
     if args.graph:
         try:
-            graphed = model.capture(**batch, multimask_output=True, overlap_branches=overlap)
+            graphed = model.capture(**batch, multimask_output=mm, overlap_branches=overlap)
             if not args.host_inputs:                     # resident inputs: the batch IS the graph's input buffers (no per-step D2D copy)
                 batch = dict(zip(("query_image_inputs", "support_image_inputs", "change_text_inputs", "support_mask_inputs"), graphed.static_in))
             launch_mode = "hipGraph replay of the forward (model.capture" + (", support branch as a parallel graph branch" if overlap else "") + "); similarity search eager"
@@ -184,18 +308,21 @@ def main():
             h2d.stage(host_batch)                      # next step's inputs start crossing PCIe now, on the copy stream
         else:
             b = batch
-        masks, emb, feat = graphed(**b) if graphed is not None else model(**b, multimask_output=True)
-        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B)    # results on rank 0 (merged once)
+        masks, emb, feat = graphed(**b) if graphed is not None else model(**b, multimask_output=mm)
+        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B, timing=timing)    # results on rank 0 (merged once)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    timing = None
     for _ in range(args.warmup):
         step()
     barrier()
     prof = []
+    timing = [] if world > 1 else None                   # per-step marks around the two collectives and the shard search
+    clock = utils.ClockSampler(dev).start()
     if graphed is None:
         ops.GEMM_PROFILE = prof                          # HIP events around every cor_gemm, on the launch stream
     t0 = time.perf_counter()
@@ -203,7 +330,10 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    clk = clock.stop()
     ops.GEMM_PROFILE = None
+    coll = retrieval.resolve_timing(timing) if timing else None
+    timing = None
     events_from = "the timed region"
     if graphed is not None:
         # the same kernels, launched eagerly so that events can bracket every GEMM (not part of `value`)
@@ -211,7 +341,7 @@ def main():
         ops.GEMM_PROFILE = prof
         engine.OVERLAP_BRANCHES = False                  # one stream: a GEMM's events then bracket that GEMM alone
         for _ in range(args.steps):
-            model(**batch, multimask_output=True)
+            model(**batch, multimask_output=mm)
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = None
     if world > 1:
@@ -253,13 +383,28 @@ def main():
                          "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
         }
         res["config"]["launch"] = launch_mode
+        res["config"]["multimask_output"] = mm
         res["roofline"]["events"] = events_from
+        res["clock"] = clk
+        if world > 1:
+            res["rccl"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), **coll,
+                               note="rank 0's means over the timed steps; device events on the launch stream under nccl (= RCCL), host clocks under the "
+                                    "gloo rehearsal (whose collectives work on host copies); collective_ms = query all-gather + packed-list gather")
         if world == 1 and not args.no_cpu_baseline:
-            with torch.no_grad():                        # the benchmarked pipeline's features of this batch (graph replay when --graph 1)
-                feat_fast = (graphed(**batch) if graphed is not None else model(**batch, multimask_output=True))[2][:, 0].clone()
-            res["cpu_baseline"], rec = cpu_baseline_and_recall(args, model, batch, rows_all, dev, feat_fast)
-            res["recall_at_1"] = rec["recall_at_1"]
-            res["recall"] = rec
+            try:                                         # a failure in the checker legs must not discard the measured throughput
+                with torch.no_grad():                    # the benchmarked pipeline's features of this batch (graph replay when --graph 1)
+                    feat_fast = (graphed(**batch) if graphed is not None else model(**batch, multimask_output=mm))[2][:, 0].clone()
+                res["cpu_baseline"], rec = cpu_baseline_and_recall(args, model, batch, rows_all, dev, feat_fast)
+                stated = stated_cpu_baseline()
+                if stated:
+                    res["cpu_baseline"]["stated_protocol"] = stated
+                res["recall_at_1"] = rec["recall_at_1"]
+                res["cpu_oracle_recall_at_1"] = rec["cpu_oracle_recall_at_1"]
+                res["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] = rec["fp32_mode_topk_index_mismatches_vs_cpu_oracle"]
+                res["recall"] = rec
+            except Exception as e:                       # noqa: BLE001
+                res["cpu_baseline"] = None
+                res["recall"] = dict(error=f"{type(e).__name__}: {e}")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -80,8 +80,39 @@ def _unpack_lists(p: torch.Tensor):
     return p[..., 0].contiguous().view(torch.float32), p[..., 1:].contiguous().view(torch.int64).squeeze(-1)
 
 
+class _Marks:
+    """Time marks of one distributed_search call (bench.py's `rccl` record): device events on the CURRENT stream under RCCL
+    (torch's collectives run on their own stream, but the blocking forms make the current stream wait for them, so events on the
+    current stream bracket them), host clocks under gloo (whose collectives work on host copies and synchronise anyway)."""
+
+    def __init__(self, dev, host):
+        self.dev, self.host, self.t = dev, host, []
+
+    def mark(self):
+        if self.host:
+            import time
+            self.t.append(time.perf_counter())
+        else:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.t.append(ev)
+
+    def ms(self, a, b):
+        return (self.t[b] - self.t[a]) * 1e3 if self.host else self.t[a].elapsed_time(self.t[b])
+
+
+def resolve_timing(timing: list) -> dict:
+    """Means over the calls recorded in `timing` (after a device synchronisation): collective_ms = query all-gather + list gather,
+    search_ms = this rank's shard against all query slots (+ packing; + the host copies under gloo)."""
+    n = max(len(timing), 1)
+    ag = sum(m.ms(0, 1) for m in timing) / n
+    se = sum(m.ms(1, 2) for m in timing) / n
+    ga = sum(m.ms(2, 3) for m in timing) / n
+    return dict(calls=len(timing), allgather_ms=ag, search_ms=se, gather_ms=ga, collective_ms=ag + ga)
+
+
 def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int, group=None, max_local: int | None = None,
-                       dst: int | None = 0):
+                       dst: int | None = 0, timing: list | None = None):
     """All ranks call this with their own queries [B_local, C] and their gallery shard.
 
     Two collectives in all, as BASELINE.json's north_star describes it:
@@ -94,8 +125,11 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
          the host in the middle of the step) and the packed per-shard lists ([slots,k,3] int32 = 12 B per entry) go to rank
          `dst` in ONE gather, where they are merged ONCE on the host by (score desc, global index asc). dst=None: all-gather
          instead, every rank merges.
-    Host synchronisation: none on the ranks that return (None, None); on `dst` exactly one device-to-host copy at the very
-    end (lists + per-rank counts in one buffer) - the next step's forward can be enqueued before it is awaited.
+    Host synchronisation (backend nccl = RCCL): none on the ranks that return (None, None); on `dst` exactly one device-to-host
+    copy at the very end (lists + per-rank counts in one buffer) - the next step's forward can be enqueued before it is awaited.
+    Under the gloo REHEARSAL backend the collectives work on host copies, so every rank synchronises twice (queries, lists).
+    `max_local` must be given (and equal on all ranks) whenever per-rank query counts can differ: the all-gather is fixed-size.
+    timing: a list that receives one _Marks per call (resolve_timing() turns them into milliseconds after a synchronisation).
     Returns (scores f32[B_total,k], idx i64[B_total,k]) CPU tensors, queries ordered by rank, on rank `dst` (every rank
     for dst=None); (None, None) on the other ranks."""
     import torch.distributed as dist
@@ -115,18 +149,29 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
     block[:b_local] = q.to(cdev)
     block[cap, 0] = float(b_local)
     allb = torch.empty((world * (cap + 1), C), dtype=torch.float32, device=cdev)
+    marks = _Marks(dev, host_coll) if timing is not None else None
+    if marks:
+        marks.mark()
     dist.all_gather_into_tensor(allb, block, group=group)        # collective 1 (RCCL over xGMI)
+    if marks:
+        marks.mark()
     allb = allb.view(world, cap + 1, C)
     slots = allb[:, :cap].reshape(world * cap, C).to(dev)        # every slot is scored; counts stay where they are
     s, i = shard.search(slots, k)                                # local shard vs ALL query slots
     packed = _pack_lists(s, i).to(cdev)
+    if marks:
+        marks.mark()
     if dst is None:
         parts = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=torch.int32, device=cdev)
         dist.all_gather_into_tensor(parts, packed, group=group)  # collective 2 (all ranks merge)
         parts = parts.view((world,) + tuple(packed.shape))
+        if marks:
+            marks.mark(); timing.append(marks)
     else:
         glist = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
         dist.gather(packed, glist, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)   # collective 2
+        if marks:
+            marks.mark(); timing.append(marks)
         if rank != dst:
             return None, None
         parts = torch.stack(glist, dim=0)

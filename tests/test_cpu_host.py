@@ -197,3 +197,80 @@ def test_siglip_tokenizer_with_a_locally_trained_sentencepiece_model(tmp_path):
     assert tokenizer.canonicalize_text("  A.b,C!!  d\te ") == "abc d e"
     empty = tok("?!")
     assert int(empty[0]) == 1 and bool((empty == 1).all())
+
+
+# ---- bench.py's launcher: --gpus N must start N ranks, and must refuse a mismatching WORLD_SIZE
+
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_launch_plan_and_command():
+    b = _bench()
+    assert b.launch_plan(1, {}) == ("run", None)
+    assert b.launch_plan(8, {}) == ("spawn", 8)                              # python bench.py --gpus 8: start the 8 ranks itself
+    assert b.launch_plan(8, {"WORLD_SIZE": "8"}) == ("run", None)            # the driver's torchrun form
+    assert b.launch_plan(1, {"WORLD_SIZE": "1"}) == ("run", None)
+    for gpus, env in ((8, {"WORLD_SIZE": "1"}), (1, {"WORLD_SIZE": "8"}), (2, {"WORLD_SIZE": "x"}), (0, {})):
+        assert b.launch_plan(gpus, env)[0] == "refuse"
+    cmd = b.spawn_command(4, ["--gpus", "4", "--steps", "5"], 29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5"]
+    assert b.parse(["--gpus", "2", "--backend", "gloo"]).backend == "gloo" and b.parse([]).multimask == 1
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main()")]
+    assert not re.search(r"^(import|from)\s+(torch|cor_amd)", head, flags=re.M), "the launching parent must not import torch / cor_amd at module level"
+
+
+def test_bench_gpus2_gloo_starts_two_ranks_by_itself_and_refuses_a_mismatch():
+    """`python bench.py --gpus 2 --backend gloo --launch-check` with NO WORLD_SIZE: the parent starts two ranks through
+    torch.distributed.run, they form a gloo group of 2 and rank 0's JSON line is relayed; a WORLD_SIZE that disagrees with
+    --gpus exits 2 before anything runs; failing ranks (RCCL without GPUs here) give a non-zero exit code and no result line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j == {"launch_check": True, "gpus": 2, "world_size": 2, "backend": "gloo", "rank_sum": 1}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=4 but --gpus 2" in r.stderr and r.stdout.strip() == ""
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_native_load_imports_torch_before_binding_the_library():
+    """Pins the fix of bbd0560: ONE HIP runtime per process - torch (which bundles its own libamdhip64) must be
+    imported before libcor_amd.so is bound, or the library resolves the system runtime and the first launch answers hipErrorNoDevice."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes\n"
+        "assert 'torch' not in sys.modules\n"
+        "seen = {}\n"
+        "real = ctypes.CDLL\n"
+        "def spy(path, *a, **k):\n"
+        "    if str(path).endswith('libcor_amd.so'):\n"
+        "        seen['torch_first'] = 'torch' in sys.modules\n"
+        "    return real(path, *a, **k)\n"
+        "ctypes.CDLL = spy\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from cor_amd import _native\n"
+        "_native.load()\n"
+        "assert seen == {'torch_first': True}, seen\n"
+        "print('ok')\n")
+    if not _built():
+        import __graft_entry__ as g
+        g.build()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
