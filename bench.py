@@ -203,8 +203,11 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
     gi = gi.cpu()
     # north_star's "bit-exact top-k indices" claim, end to end in the mode that can deliver it: exact-fp32 HIP forward +
     # cor_similarity_topk on the device  vs  fp32 CPU oracle forward + CPU chain top-k, same weights / inputs / gallery
-    _, gi32 = gshard.search(q_ref[:NB_CPU].to(dev).contiguous(), args.topk)
+    # (like with like: an fp32 gallery holding the stored bf16 values -> the device runs the exact fp32 fmaf chain, and so does the oracle;
+    # a 16-bit gallery would round the QUERY to bf16 on the device, which the fp32 oracle does not)
+    _, gi32 = retrieval.GalleryShard(G.float().to(dev), 0).search(q_ref[:NB_CPU].to(dev).contiguous(), args.topk)
     gi32 = gi32.cpu()
+    _, ri_cpu = oret.similarity_topk(q_cpu, G.float(), args.topk, exact_chain=True)
     rec = dict(recall_at_1=float((gi[:, 0] == ri[:, 0]).float().mean()), queries=B,
                recall_at_1_planted=float((gi[:, 0] == where).float().mean()), oracle_recall_at_1_planted=float((ri[:, 0] == where).float().mean()),
                topk_index_mismatches=int((gi != ri).sum()), topk_entries=int(ri.numel()),

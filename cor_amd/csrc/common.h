@@ -1,6 +1,7 @@
 // cor_amd — device-side helpers shared by all gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/cor_amd.h"
@@ -142,20 +143,25 @@ static inline int cor_cur_device() {
   (void)hipGetDevice(&d);
   return (d >= 0 && d < COR_MAX_DEVICES) ? d : 0;
 }
-struct DevOnce { bool done[COR_MAX_DEVICES] = {}; };
+// Several host threads may launch concurrently (the header promises it): the flags are atomics. The guarded calls are idempotent
+// (the same attribute value / the same property), so two threads that both find a flag clear may both make the call; what the
+// acquire / release pair guarantees is that a thread which sees the flag set also sees the call completed.
+struct DevOnce { std::atomic<bool> done[COR_MAX_DEVICES] = {}; };
 static inline void cor_max_dyn_lds(const void* fn, int bytes, DevOnce& once) {
   const int d = cor_cur_device();
-  if (!once.done[d]) {
+  if (!once.done[d].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    once.done[d] = true;
+    once.done[d].store(true, std::memory_order_release);
   }
 }
 static inline int cor_device_cus() {
-  static int n[COR_MAX_DEVICES] = {};
+  static std::atomic<int> n[COR_MAX_DEVICES] = {};
   const int d = cor_cur_device();
-  if (n[d] == 0) {
+  int v = n[d].load(std::memory_order_acquire);
+  if (v == 0) {
     hipDeviceProp_t prop;
-    n[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    v = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    n[d].store(v, std::memory_order_release);
   }
-  return n[d];
+  return v;
 }

@@ -174,8 +174,7 @@ inline TopkPlan2 make_plan2(int Bq, int Ng, int k, int n_cu) {
 }
 
 template <typename TG>
-__device__ __forceinline__ uint4 q_frag16(const float* qrow, int c, int h) {
-  const f32x4 lo = *(const f32x4*)(qrow + c * 16 + 8 * h), hi = *(const f32x4*)(qrow + c * 16 + 8 * h + 4);
+__device__ __forceinline__ uint4 q_frag16_vals(const f32x4 lo, const f32x4 hi) {       // 8 fp32 values -> one 16-byte K-fragment piece
   if (__is_same(TG, bf16_t)) {
     uint4 u;
     u.x = (uint32_t)f2bf(lo[0]) | ((uint32_t)f2bf(lo[1]) << 16); u.y = (uint32_t)f2bf(lo[2]) | ((uint32_t)f2bf(lo[3]) << 16);
@@ -184,6 +183,10 @@ __device__ __forceinline__ uint4 q_frag16(const float* qrow, int c, int h) {
   }
   f16x8 t = {(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
   return __builtin_bit_cast(uint4, t);
+}
+template <typename TG>
+__device__ __forceinline__ uint4 q_frag16(const float* qrow, int c, int h) {
+  return q_frag16_vals<TG>(*(const f32x4*)(qrow + c * 16 + 8 * h), *(const f32x4*)(qrow + c * 16 + 8 * h + 4));
 }
 
 template <typename TG, int KMAX>
@@ -317,7 +320,9 @@ struct ScanArgs {
   int Bq, Ng, nqg, nsplit, tiles_per_split;
   int ntiles;                      // 64-row super-tiles this launch walks (SAMPLE: sample super-tiles; APPEND: all of them)
   int tile_stride;                 // super-tiles between consecutive walked super-tiles (SAMPLE: >= 1; APPEND: 1)
-  const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep)
+  const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep, or the SAMPLE pass itself)
+  const float* q_f32;              // SAMPLE only, or null: convert the fp32 queries here, publish the image (blocks of slice 0) and clear the flags
+  uint4* qimg_w; int* flags;
   float* pmax; int ngroups;        // SAMPLE: pmax[q * ngroups + split * 2 + h]
   float tau_add;                   // 0; timing-only ablation (COR_TOPK_DEBUG_NOCAND): +1e30 = no candidate ever passes
   const float* tau; int* cnt; float* rec_s; int* rec_g; int cap;     // APPEND: record i of stream (q, slice, half): 16 scores + first row
@@ -359,12 +364,25 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     // K-fragments from the fragment-major image sim_prep wrote (query block, K-step, lane) x 16 B: 1 KiB per wave-instruction,
     // 16 of them per query block (reading the fp32 rows cost every CU 512 KiB of L2 traffic per launch: ~7 us)
     const uint4* qimg = a.qimg + ((long)(q0 / 32 + qb) * 16) * 64 + lane;
+    if (SAMPLE && a.q_f32) {
+      // no sim_prep launch: this pass converts the fp32 rows itself (a 5.6-us launch + boundary saved for ~3.5 us more L2 traffic
+      // here), and the blocks of gallery slice 0 publish the fragment-major image the APPEND pass reads
+      const float* qrow = a.q_f32 + (long)min(q0 + qb * 32 + r, a.Bq - 1) * C;
+      uint4* wimg = a.qimg_w + ((long)(q0 / 32 + qb) * 16) * 64 + lane;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
+      for (int c = 0; c < 16; ++c) {
+        qf[qb][c] = active ? q_frag16<TG>(qrow, c, h) : make_uint4(0, 0, 0, 0);
+        if (active && split == 0) wimg[c * 64] = qf[qb][c];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
+    }
     const int q = min(q0 + qb * 32 + r, a.Bq - 1);
     tau[qb] = SAMPLE ? 0.f : a.tau[q] + a.tau_add;
     gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
+  if (SAMPLE && a.q_f32 && blockIdx.x == 0 && tid == 0) a.flags[0] = 0;     // per-call overflow flag (sim_prep's other duty)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
   const unsigned wbase = (unsigned)wave * 1024u;       // this wave's first slot (bytes) per 8-KiB pass
   int st_row[4], st_src[4];                            // a super-tile = 64 rows x 512 B = four 8-KiB passes of the block
@@ -498,6 +516,11 @@ __global__ void __launch_bounds__(256) sim_prep(const float* __restrict__ Q, int
   }
 }
 
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f_floor(unsigned key) {      // the smallest float whose order-preserving key is >= key's prefix
+  const unsigned u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+  return __uint_as_float(u);
+}
 template <typename TG> __device__ __forceinline__ float round_to(float x);
 template <> __device__ __forceinline__ float round_to<bf16_t>(float x) { return bf2f(f2bf(x)); }
 template <> __device__ __forceinline__ float round_to<_Float16>(float x) { return (float)(_Float16)x; }
@@ -513,29 +536,28 @@ __global__ void __launch_bounds__(256) sim_tau(const float* __restrict__ Q, cons
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const float v = round_to<TG>(Q[(long)q * 256 + lane * 4 + i]); nrm = fmaf(v, v, nrm); }
   nrm = sqrtf(wave_sum(nrm));
-  float v[8];
+  // k-th largest of the group maxima, floored to 20 key bits (any lower bound of it is valid): counting binary search - every
+  // step is 8 compares + 8 ballots + scalar bit counts (the round-2 form ran k rounds of a 6-step ds_bpermute maximum: ~3.5 us of
+  // dependent LDS round trips per query)
+  unsigned key[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = (lane + 64 * i < ngroups) ? pmax[(long)q * ngroups + lane + 64 * i] : -INFINITY;
+  for (int i = 0; i < 8; ++i) key[i] = f2key((lane + 64 * i < ngroups) ? pmax[(long)q * ngroups + lane + 64 * i] : -INFINITY) >> 12;
   float kth = -INFINITY;
   if (ngroups >= k) {
-    for (int round = 0; round < k; ++round) {
-      float m = v[0];
+    unsigned lo = 0x007FFu, hi = 0x100000u;             // 0x007FF = key prefix of -inf
+#pragma unroll 1
+    for (int it = 0; it < 20; ++it) {
+      const unsigned mid = (lo + hi) >> 1;
+      int c = 0;
 #pragma unroll
-      for (int i = 1; i < 8; ++i) m = fmaxf(m, v[i]);
-      kth = wave_max(m);
-      // remove ONE instance of the maximum: the first lane holding it clears its first copy
-      const unsigned long long owners = __builtin_amdgcn_ballot_w64(m == kth);
-      if (lane == __builtin_ctzll(owners)) {
-        bool done = false;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (!done && v[i] == kth) { v[i] = -INFINITY; done = true; }
-      }
+      for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] >= mid));
+      if (c >= k) lo = mid; else hi = mid;
     }
+    kth = lo == 0x007FFu ? -INFINITY : key2f_floor(lo << 12);
   }
   if (lane == 0) tau[q] = kth - SIM_DELTA * fmaxf(1.f, nrm);      // -inf stays -inf
 }
 
-__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
 // chain score of gallery row `idx` against the query in LDS (oracle/c/sim_chain.c order: chunk c of 8: k = 8c+i then 8c+4+i)
 template <typename TG>
@@ -565,13 +587,14 @@ __device__ __forceinline__ float chain_score(const TG* __restrict__ G, long idx,
 
 // Exact fallback of ONE query (block of 256 threads): every row's chain score, per-thread sorted top-k lists in LDS (thread t
 // owns slots [t*k, t*k + k) of cs/ci: 256 * k <= FS_MAX), then k rounds of block-wide arg-best by (score desc, index asc).
-template <typename TG>
+template <typename TG, int NT = 256>
 __device__ void brute_force_topk(const TG* __restrict__ G, int Ng, const float* qs, float* cs, int* ci, int k, long long g_offset,
                                  float* out_s, long long* out_i) {
-  __shared__ float rs[4]; __shared__ int ri[4], rp[4];
+  constexpr int NW = NT / 64;
+  __shared__ float rs[NW]; __shared__ int ri[NW], rp[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = tid * k;
   for (int j = 0; j < k; ++j) { cs[base + j] = -INFINITY; ci[base + j] = INT_MAX; }
-  for (int g = tid; g < Ng; g += 256) {                  // ascending rows: a tie keeps the earlier (smaller) index ahead
+  for (int g = tid; g < Ng; g += NT) {                  // ascending rows: a tie keeps the earlier (smaller) index ahead
     const float sc = chain_score<TG>(G, g, qs);
     if (sc > cs[base + k - 1]) {
       int j = k - 1;
@@ -580,10 +603,10 @@ __device__ void brute_force_topk(const TG* __restrict__ G, int Ng, const float* 
     }
   }
   __syncthreads();
-  const int n = 256 * k;
+  const int n = NT * k;
   for (int round = 0; round < k; ++round) {
     float bs = -INFINITY; int bi = INT_MAX, bp = -1;
-    for (int i = tid; i < n; i += 256)
+    for (int i = tid; i < n; i += NT)
       if (ci[i] != INT_MAX && (bp < 0 || cs[i] > bs || (cs[i] == bs && ci[i] < bi))) { bs = cs[i]; bi = ci[i]; bp = i; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -594,7 +617,7 @@ __device__ void brute_force_topk(const TG* __restrict__ G, int Ng, const float* 
     __syncthreads();
     if (tid == 0) {
       float fs = rs[0]; int fi = ri[0], fp = rp[0];
-      for (int w = 1; w < 4; ++w) if (rp[w] >= 0 && (fp < 0 || rs[w] > fs || (rs[w] == fs && ri[w] < fi))) { fs = rs[w]; fi = ri[w]; fp = rp[w]; }
+      for (int w = 1; w < NW; ++w) if (rp[w] >= 0 && (fp < 0 || rs[w] > fs || (rs[w] == fs && ri[w] < fi))) { fs = rs[w]; fi = ri[w]; fp = rp[w]; }
       out_s[round] = fp >= 0 ? fs : -INFINITY;
       out_i[round] = fp >= 0 ? (long long)fi + g_offset : -1LL;
       if (fp >= 0) ci[fp] = INT_MAX;
@@ -771,6 +794,418 @@ __global__ void __launch_bounds__(256) sim_topk_merge(const float* ws_s, const i
 
 inline int device_cus() { return cor_device_cus(); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v4 (16-bit galleries, C = 256, SMALL shards - the 8-GPU shard shapes of BASELINE configs[2], 256..512 x 12.5k - and few queries
+// against up to ~130k rows): TWO launches and LOCAL thresholds instead of prep -> sample scan -> tau -> append scan -> final.
+//   sim_block_scan: a block = 32 * QB queries x one gallery slice of 256 * T rows. Every wave owns ALL the block's queries (their
+//     K-fragments in registers) and 32 * T rows of its own, which reach its PRIVATE 16-KiB LDS buffer by LDS-DMA in K-half tiles
+//     (no block barrier inside the scan); the 16 * T * QB scores of a lane STAY IN REGISTERS. The block then knows, per query, 64
+//     disjoint row classes' maxima; their k-th largest is a lower bound of the query's k-th best score over the whole shard (k
+//     classes each hold a row at least that good), so rows below it minus delta_q cannot be in the answer: the lanes append the
+//     few registers that pass (~k per query and slice) to per-(query, slice) lists. No sample pass, no global threshold, no
+//     second scan, no atomics on global memory.
+//   sim_final_wave: ONE WAVE per query gathers its lists, finds the k-th best MFMA score by a counting binary search, re-scores
+//     the short list with the exact fp32 fmaf chain (rows staged by LDS-DMA, all in flight at once) and ranks it.
+// Exactness (same argument as v3, with the slice's own threshold): let T_b be the k-th best MFMA score inside slice b. The k best
+// rows of slice b have chain scores >= T_b - eps, so the shard's k-th best chain score is >= T_b - eps for EVERY b; a row g of the
+// exact answer therefore has MFMA score >= T_b(g) - 2 eps >= tau_b(g) - delta and is appended by its block. Every row of the MFMA
+// top-k is appended too (global k-th best >= local k-th best), so the final's T is the shard's k-th best MFMA score and the short
+// list {MFMA score >= T - delta} holds the exact answer. A kernel boundary between the two costs ~1.5 us; keeping the selection in
+// the scan launch would need an agent-scope release + counter + acquire (~3.4 us by the MI355X guide's price list) and one block
+// ranking 32-64 queries: measured choice, see DESIGN 3.4.
+constexpr int SB_NC = 4096;                            // candidates per query held in LDS by sim_final_wave (32 KiB)
+constexpr int SB_SL = 64;                              // short list (one entry per lane)
+
+struct SmallPlan {
+  bool ok;
+  int qb, T, nqg, nslices, cap, grid, xcd_map;
+  size_t off_flags, off_ovf, off_cnt, off_cand, bytes;
+};
+inline SmallPlan make_small(int Bq, int Ng, int k) {
+  SmallPlan p{};
+  p.qb = Bq > 32 ? 2 : 1;
+  p.nqg = cdiv(Bq, 32 * p.qb);
+  const int tmax = p.qb == 2 ? 2 : 4;                  // accumulators: 16 * T * QB <= 64 registers
+  int target = device_cus() / p.nqg;                   // about one block per CU
+  if (target < 1) target = 1;
+  int t = cdiv(cdiv(Ng, target), 256);
+  p.T = t <= 1 ? 1 : (t == 2 ? 2 : tmax);              // instantiated: 1, 2, (4 for QB = 1)
+  if (p.T > tmax) p.T = tmax;
+  p.nslices = cdiv(Ng, 256 * p.T);
+  p.cap = k <= 12 ? 64 : 160;                          // entries per (query, slice) list: ~k + 2 expected
+  p.xcd_map = p.nslices >= 8 ? 1 : 0;                  // blocks that share a gallery slice share an XCD (its L2)
+  p.grid = p.nqg * (p.xcd_map ? ((p.nslices + 7) & ~7) : p.nslices);
+  p.ok = (long)p.nslices * (k + 8) * 13 / 10 <= 3072 && p.grid <= 65535 * 8;
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
+  p.off_flags = take(16);
+  p.off_ovf = take((size_t)Bq * 4);
+  p.off_cnt = take((size_t)Bq * p.nslices * 4);
+  p.off_cand = take((size_t)Bq * p.nslices * p.cap * 8);
+  p.bytes = o;
+  return p;
+}
+
+
+template <typename TG, int QB, int T>
+__global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict__ Q, const TG* __restrict__ G, int Bq, int Ng, int k, int nqg,
+                                                         int nslices, int xcd_map, int cap, int* __restrict__ cnt, uint2* __restrict__ cand,
+                                                         int* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int QPB = 32 * QB, ZB = QB * 16 * 64 * 16, TPQ = 512 / QPB, FPT = 256 / TPQ, VPT = 64 / TPQ, CS = QPB + 1;
+  constexpr int RPW = 32 * T, RPB = 8 * RPW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  int slice, qg;
+  if (xcd_map) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; slice = (j / nqg) * 8 + x; qg = j % nqg; }
+  else { slice = blockIdx.x / nqg; qg = blockIdx.x % nqg; }
+  if (slice >= nslices) return;                        // padding blocks of the XCD mapping (whole block, before any barrier)
+  if (blockIdx.x == 0 && tid == 0) flags[0] = 0;       // per-call overflow flag (the final kernel runs behind this one)
+  const int q0 = qg * QPB;
+  const long w0 = (long)slice * RPB + wave * RPW;      // this wave's first gallery row
+  int ntw = (int)((Ng - w0 + 31) / 32);                // 32-row tiles of this wave inside the shard (wave-uniform)
+  ntw = ntw < 0 ? 0 : (ntw > T ? T : ntw);
+  const int nsteps = 2 * ntw;                          // K-half tiles
+
+  char* Z = smem;                                      // query image (prologue), then class maxima / thresholds / list counters
+  char* Aw = smem + ZB + wave * 16384;                 // this wave's two 8-KiB K-half buffers (32 rows x 256 B)
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)Aw));
+  const int rowl = lane >> 4, sl = lane & 15;
+  auto issue = [&](int s) {                            // K-half tile s = 2 t + p -> buffer p. LDS image lane-linear: 4 rows x 256 B per
+    const int t = s >> 1, p = s & 1;                   // wave-instruction; slot sl of row `row` holds source chunk sl ^ (row & 15)
+    const long g0 = w0 + 32 * t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + rowl;
+      long gr = g0 + row;
+      gr = gr < Ng ? gr : (long)Ng - 1;                // clamped duplicates are masked to -inf below
+      glds16(G + gr * 256 + ((sl ^ (row & 15)) + 16 * p) * 8, __builtin_amdgcn_readfirstlane(ldsA + p * 8192 + 1024 * i));
+    }
+  };
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+
+  // queries -> gallery dtype, MFMA-fragment order in Z: image[(qblk * 16 + c) * 64 + lane'] = q[qblk*32 + (lane'&31)][16c + 8(lane'>>5) ..+8]
+  // thread (query qq, part pp) converts FPT consecutive values: whole 16-value K-steps c = pp * FPT / 16 ...
+  const int qq = tid / TPQ, pp = tid % TPQ;
+  float nrm2 = 0.f;
+  {
+    const float* qrow = Q + (long)min(q0 + qq, Bq - 1) * 256 + pp * FPT;
+#pragma unroll
+    for (int j = 0; j < FPT / 8; ++j) {                // one 16-byte fragment piece = 8 values
+      const f32x4 lo = *(const f32x4*)(qrow + 8 * j), hi = *(const f32x4*)(qrow + 8 * j + 4);
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float x = round_to<TG>(v[i]); nrm2 = fmaf(x, x, nrm2); }
+      const int kpos = pp * FPT + 8 * j, c = kpos >> 4, hh = (kpos >> 3) & 1;
+      ((uint4*)Z)[((qq >> 5) * 16 + c) * 64 + hh * 32 + (qq & 31)] = q_frag16_vals<TG>(lo, hi);
+    }
+#pragma unroll
+    for (int o = 1; o < TPQ; o <<= 1) nrm2 += __shfl_xor(nrm2, o, 64);   // the TPQ threads of a query are adjacent lanes: every one holds |q|^2
+  }
+  __syncthreads();
+  uint4 qf[QB][16];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) qf[qb][c] = ((const uint4*)Z)[(qb * 16 + c) * 64 + lane];
+  __syncthreads();                                     // Z is free from here on
+
+  f32x16 acc[QB][T];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[qb][t][e] = 0.f;
+  const int rd_base = r * 256 + (((h ^ r) & 1) << 4), rd_x = (r >> 1) & 7;     // chunk (2c' + h) ^ (r & 15) of row r
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t < ntw) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int s = 2 * t + p;
+        // K-half tile s has landed once at most the 8 copies of tile s + 1 are outstanding (VMEM retires in order)
+        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* buf = Aw + p * 8192;
+        uint4 af[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + rd_base + ((c ^ rd_x) << 5));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint4 av = af[c & 3];
+          if (c + 4 < 8) af[c & 3] = *(const uint4*)(buf + rd_base + (((c + 4) ^ rd_x) << 5));
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            if (__is_same(TG, bf16_t))
+              acc[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][8 * p + c]), acc[qb][t], 0, 0, 0);
+            else
+              acc[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][8 * p + c]), acc[qb][t], 0, 0, 0);
+          }
+        }
+        if (s + 2 < nsteps) {                          // buffer p is consumed (its reads fed the MFMAs above): refill it two steps ahead
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          issue(s + 2);
+        }
+      }
+    }
+  }
+  // rows beyond the shard (clamped duplicates, absent tiles) never count; class maxima: register e over the wave's tiles, 16 -> 4
+  float* cmx = (float*)Z;                              // [64 classes][CS]: class = (wave * 2 + h) * 4 + j ; padded stride: conflict-free both ways
+  float* thr = cmx + 64 * CS;                          // [QPB]
+  int* lcnt = (int*)(thr + QPB);                       // [QPB]
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float cm[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const long row = w0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (t >= ntw || row >= Ng) acc[qb][t][e] = -INFINITY;
+        m = fmaxf(m, acc[qb][t][e]);
+      }
+      cm[e] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      cmx[((wave * 2 + h) * 4 + j) * CS + qb * 32 + r] = fmaxf(fmaxf(cm[j], cm[j + 4]), fmaxf(cm[j + 8], cm[j + 12]));
+  }
+  __syncthreads();
+  // tau_q = (k-th largest of the 64 class maxima, floored to 16 key bits) - delta_q: counting binary search, TPQ lanes per query
+  {
+    unsigned keys[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) keys[i] = f2key(cmx[(pp * VPT + i) * CS + qq]) >> 16;
+    unsigned lo = 0x007Fu, hi = 0x10000u;             // 0x007F = key prefix of -inf: "fewer than k classes hold a row"
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+      const unsigned mid = (lo + hi) >> 1;
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) c += keys[i] >= mid ? 1 : 0;
+#pragma unroll
+      for (int o = 1; o < TPQ; o <<= 1) c += __shfl_xor(c, o, 64);
+      if (c >= k) lo = mid; else hi = mid;
+    }
+    if (pp == 0) {
+      const float tau = lo == 0x007Fu ? -INFINITY : key2f_floor(lo << 16);
+      thr[qq] = tau - SIM_DELTA * fmaxf(1.f, sqrtf(nrm2));
+      lcnt[qq] = 0;
+    }
+  }
+  __syncthreads();
+  // append the registers that pass to the block's per-query lists (the A buffers are free: every wave is past its scan)
+  uint2* lst = (uint2*)(smem + ZB);                    // [QPB][cap]
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int ql = qb * 32 + r;
+    const float tq = thr[ql];
+    const bool live = q0 + ql < Bq;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float tmax = max3f(acc[qb][t][0], acc[qb][t][1], acc[qb][t][2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, acc[qb][t][e], acc[qb][t][e + 1]);
+      tmax = fmaxf(tmax, acc[qb][t][15]);
+      if (__builtin_amdgcn_ballot_w64(live && tmax >= tq && tmax > -INFINITY) == 0) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[qb][t][e];
+        if (live && v >= tq && v > -INFINITY) {
+          const int slot = atomicAdd(&lcnt[ql], 1);
+          if (slot < cap) lst[ql * cap + slot] = make_uint2(__float_as_uint(v), (unsigned)(w0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (q0 + qq < Bq) {
+    const int n_raw = lcnt[qq], n = min(n_raw, cap);
+    const long li = (long)(q0 + qq) * nslices + slice;
+    if (pp == 0) cnt[li] = n_raw;                      // > cap: sim_final_wave sees the overflow
+    for (int j = pp; j < n; j += TPQ) cand[li * cap + j] = lst[qq * cap + j];
+  }
+}
+
+// chain score of a gallery row staged in LDS (32 chunks of 16 B; chunk c sits in slot c ^ x): the order of oracle/c/sim_chain.c
+template <typename TG>
+__device__ __forceinline__ float chain_score_lds(const char* row, int x, const float* qs) {
+  float acc = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < 32; ++c) {
+    const uint4 v = *(const uint4*)(row + ((c ^ x) << 4));
+    const f32x4 qa = *(const f32x4*)(qs + 8 * c), qb = *(const f32x4*)(qs + 8 * c + 4);
+    float g[8];
+    if (__is_same(TG, bf16_t)) {
+      g[0] = __uint_as_float(v.x << 16); g[1] = __uint_as_float(v.x & 0xffff0000u); g[2] = __uint_as_float(v.y << 16); g[3] = __uint_as_float(v.y & 0xffff0000u);
+      g[4] = __uint_as_float(v.z << 16); g[5] = __uint_as_float(v.z & 0xffff0000u); g[6] = __uint_as_float(v.w << 16); g[7] = __uint_as_float(v.w & 0xffff0000u);
+    } else {
+      const f16x8 hv = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = (float)hv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = fmaf(g[i], qa[i], acc);
+      acc = fmaf(g[4 + i], qb[i], acc);
+    }
+  }
+  return acc;
+}
+
+// ONE WAVE per query: gather the candidates, select, re-score exactly, rank. Two gather front ends: RECORDS = false: the
+// per-(query, slice) entry lists of sim_block_scan (cnt / cand; nl = slices); RECORDS = true: the per-(query, stream) records of
+// sim_scan<APPEND> (cnt / rec_s / rec_g; nl = streams; a record = the 16 scores of one lane's accumulator column + the tile's
+// first row; the scores >= tau_q are kept).
+template <typename TG, bool RECORDS>
+__global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q, const TG* __restrict__ G, const int* __restrict__ cnt,
+                                                     const uint2* __restrict__ cand, const float* __restrict__ rec_s, const int* __restrict__ rec_g,
+                                                     const float* __restrict__ tau, int nslices, int cap, int Ng, int k, long long g_offset,
+                                                     float* out_s, long long* out_i, int* flags, int* ovf_q, int no_fallback) {
+  __shared__ __attribute__((aligned(16))) float cs[SB_NC];
+  __shared__ __attribute__((aligned(16))) int ci[SB_NC];
+  __shared__ __attribute__((aligned(16))) char rows[32 * 512];
+  __shared__ __attribute__((aligned(16))) float qs[256];
+  __shared__ float sl_s[SB_SL];
+  __shared__ int sl_i[SB_SL];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  {
+    const f32x4 v = *(const f32x4*)(Q + (long)q * 256 + 4 * lane);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float x = round_to<TG>(v[i]); qs[4 * lane + i] = x; n2 = fmaf(x, x, n2); }
+    n2 = wave_sum(n2);
+    sl_s[lane] = n2;                                   // (parked: read back as delta below, after the barrier)
+  }
+  int n = 0;
+  bool ovf = false;
+  if (RECORDS) {
+    // 1r. lane <-> stream; record 0 of every stream is fetched TOGETHER with the stream's count (most streams hold 0 or 1 records):
+    // one global round trip instead of three dependent ones. Register e of lane half h4 / 4 is row g0 + (e&3) + 8 (e>>2) + h4.
+    __shared__ int total;
+    if (lane == 0) total = 0;
+    __syncthreads();
+    const float tq = tau[q];
+    auto take = [&](const f32x4 (&v)[4], int g0, int h4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (v[g][i] >= tq && v[g][i] > -INFINITY) {
+            const int pos = atomicAdd(&total, 1);
+            if (pos < SB_NC) { cs[pos] = v[g][i]; ci[pos] = g0 + i + 8 * g + h4; }
+          }
+    };
+    for (int st = lane; st < nslices; st += 64) {
+      const long rec0 = ((long)q * nslices + st) * cap;
+      const f32x4* src = (const f32x4*)(rec_s + rec0 * 16);
+      const f32x4 v0[4] = {src[0], src[1], src[2], src[3]};
+      const int g00 = rec_g[rec0];
+      const int c = cnt[(long)q * nslices + st];
+      if (c > cap) ovf = true;
+      const int nrec = min(c, cap), h4 = 4 * (st & 1);
+      if (nrec > 0) take(v0, g00, h4);
+      for (int j = 1; j < nrec; ++j) {
+        const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 16);
+        const f32x4 vj[4] = {sj[0], sj[1], sj[2], sj[3]};
+        take(vj, rec_g[rec0 + j], h4);
+      }
+    }
+    __syncthreads();
+    n = total;
+  }
+  // 1. gather: lane <-> slice, exclusive prefix of the list lengths, then entry j of every slice per round
+  for (int s0 = 0; !RECORDS && s0 < nslices; s0 += 64) {
+    const int s = s0 + lane;
+    int c = s < nslices ? cnt[(long)q * nslices + s] : 0;
+    if (c > cap) { ovf = true; c = cap; }
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const int off = n + incl - c;
+    int cmax = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+    const uint2* src = cand + ((long)q * nslices + (s < nslices ? s : 0)) * cap;
+    for (int j = 0; j < cmax; ++j) {
+      if (j < c && off + j < SB_NC) { const uint2 e = src[j]; cs[off + j] = __uint_as_float(e.x); ci[off + j] = (int)e.y; }
+    }
+    n += __builtin_amdgcn_readlane(incl, 63);
+  }
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (__builtin_amdgcn_ballot_w64(ovf) != 0 || n > SB_NC) ovf = true; else ovf = false;
+  __syncthreads();
+  const float delta = SIM_DELTA * fmaxf(1.f, sqrtf(sl_s[0]));
+  __syncthreads();
+  // 2. T_lo <= T = k-th best MFMA score: counting binary search over the top 20 key bits (n <= k: every candidate is in)
+  float T = -INFINITY;
+  int m = 0;
+  if (!ovf) {
+    if (n > k) {
+      unsigned lo = 0x007FFu, hi = 0x100000u;
+#pragma unroll 1
+      for (int it = 0; it < 20; ++it) {
+        const unsigned mid = (lo + hi) >> 1;
+        int c = 0;
+        for (int i = lane; i < n; i += 64) c += (f2key(cs[i]) >> 12) >= mid ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (c >= k) lo = mid; else hi = mid;
+      }
+      T = lo == 0x007FFu ? -INFINITY : key2f_floor(lo << 12);
+    }
+    // 3. short list: MFMA score >= T - delta (ballot compaction; order irrelevant: the ranking below is total)
+    const float cut = T - delta;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool pass = i < n && cs[i] >= cut && cs[i] > -INFINITY;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+      const int pos = m + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      if (pass && pos < SB_SL) sl_i[pos] = ci[i];
+      m += __builtin_popcountll(bal);
+    }
+    if (m > SB_SL) ovf = true;
+  }
+  __syncthreads();
+  if (ovf) {
+    if (lane == 0) { ovf_q[q] = 1; atomicOr(flags, 1); }
+    if (no_fallback) {
+      for (int j = lane; j < k; j += 64) { out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -2LL; }
+      return;
+    }
+    brute_force_topk<TG, 64>(G, Ng, qs, cs, ci, k, g_offset, out_s + (long)q * k, out_i + (long)q * k);
+    return;
+  }
+  if (lane == 0) ovf_q[q] = 0;
+  // 4. exact re-scoring, 32 rows per round: the rows arrive by LDS-DMA (2 rows per wave-instruction, all in flight at once;
+  // slot (lane & 31) of row j is fed from source chunk (lane & 31) ^ j), then lane j runs the chain over its row
+  const unsigned ldsR = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)rows));
+  for (int base = 0; base < m; base += 32) {
+    const int nr = min(32, m - base);
+#pragma unroll 1
+    for (int i = 0; 2 * i < nr; ++i) {
+      const int jj = 2 * i + (lane >> 5);
+      const long idx = sl_i[base + min(jj, nr - 1)];
+      glds16(G + idx * 256 + (((lane & 31) ^ jj) << 3), __builtin_amdgcn_readfirstlane(ldsR + 1024 * i));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane < nr) sl_s[base + lane] = chain_score_lds<TG>(rows + lane * 512, lane, qs);
+    __syncthreads();
+  }
+  // 5. rank by (chain score desc, index asc); entries beyond the short list (Ng < k) are (-inf, -1)
+  if (lane < m) {
+    const float s = sl_s[lane]; const int idx = sl_i[lane];
+    int rank = 0;
+    for (int i = 0; i < m; ++i) rank += (sl_s[i] > s || (sl_s[i] == s && sl_i[i] < idx)) ? 1 : 0;
+    if (rank < k) { out_s[(long)q * k + rank] = s; out_i[(long)q * k + rank] = (long long)idx + g_offset; }
+  }
+  for (int j = m + lane; j < k; j += 64) { out_s[(long)q * k + j] = -INFINITY; out_i[(long)q * k + j] = -1LL; }
+}
+
+
 // plan of the threshold-and-append pipeline (host; shared by the launcher and cor_topk_workspace_bytes)
 struct V3Plan {
   int qb, nqg;                       // query blocks per wave (1 | 2), query groups of 256 * qb
@@ -862,11 +1297,16 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
   float* rec_s = (float*)(w + p.off_recs); int* rec_g = (int*)(w + p.off_recg);
   uint4* qimg = (uint4*)(w + p.off_img);
-  // 0. queries -> gallery dtype, fragment-major; clears the per-call overflow flags
-  hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
-  COR_CHECK_LAUNCH();
+  // 0. queries -> gallery dtype, fragment-major; clears the per-call overflow flags. Only when no SAMPLE pass runs (tiny shards on
+  // the forced global-threshold path) or for the round-2 selection kernel: otherwise the SAMPLE pass does it (one launch fewer)
+  const bool use_prep = p.ngroups == 0 || (flags & COR_TOPK_BLOCK_FINAL);
+  if (use_prep) {
+    hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
+    COR_CHECK_LAUNCH();
+  }
   ScanArgs a{};
   a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg; a.qimg = qimg;
+  a.q_f32 = use_prep ? nullptr : Q; a.qimg_w = qimg; a.flags = dflags;
   if (p.ngroups > 0) {                                  // A. group maxima of the strided sample
     a.nsplit = p.s_nsplit; a.tiles_per_split = p.s_tiles_per_split; a.ntiles = p.s_tiles; a.tile_stride = p.s_stride;
     a.pmax = pmax; a.ngroups = p.ngroups;
@@ -881,11 +1321,40 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   a.tau = tau; a.cnt = cnt; a.rec_s = rec_s; a.rec_g = rec_g; a.cap = p.cap; a.tau_add = (flags & 4) ? 1e30f : 0.f;
   hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, G, a);
   COR_CHECK_LAUNCH();
-  // D. exact selection
-  hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, rec_s, rec_g, tau, cnt, p.nstreams, p.cap, Ng, k, g_offset, out_s, out_i,
-                     dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
+  // D. exact selection: one wave per query (COR_TOPK_BLOCK_FINAL: the round-2 block-per-query kernel, kept as the A/B partner)
+  if (flags & COR_TOPK_BLOCK_FINAL)
+    hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, rec_s, rec_g, tau, cnt, p.nstreams, p.cap, Ng, k, g_offset, out_s, out_i,
+                       dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
+  else
+    hipLaunchKernelGGL((sim_final_wave<TG, true>), dim3(Bq), dim3(64), 0, s, Q, G, cnt, nullptr, rec_s, rec_g, tau, p.nstreams, p.cap, Ng, k, g_offset,
+                       out_s, out_i, dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
   COR_CHECK_LAUNCH();
   return 0;                                             // (an overflowed query was ranked exactly inside sim_final: no second launch)
+}
+
+template <typename TG, int QB, int T>
+int launch_small_t(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_offset, float* out_s, long long* out_i, char* w,
+                   const SmallPlan& p, int flags, hipStream_t s) {
+  constexpr size_t lds = (size_t)QB * 16 * 64 * 16 + 8 * 16384;
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)sim_block_scan<TG, QB, T>, (int)lds, once);
+  int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
+  uint2* cand = (uint2*)(w + p.off_cand);
+  hipLaunchKernelGGL((sim_block_scan<TG, QB, T>), dim3(p.grid), dim3(512), lds, s, Q, G, Bq, Ng, k, p.nqg, p.nslices, p.xcd_map, p.cap, cnt, cand, dflags);
+  COR_CHECK_LAUNCH();
+  hipLaunchKernelGGL((sim_final_wave<TG, false>), dim3(Bq), dim3(64), 0, s, Q, G, cnt, cand, nullptr, nullptr, nullptr, p.nslices, p.cap, Ng, k, g_offset,
+                     out_s, out_i, dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+template <typename TG>
+int launch_small(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_offset, float* out_s, long long* out_i, char* w,
+                 const SmallPlan& p, int flags, hipStream_t s) {
+#define SB_GO(QB_, T_) return launch_small_t<TG, QB_, T_>(Q, G, Bq, Ng, k, g_offset, out_s, out_i, w, p, flags, s)
+  if (p.qb == 1) { if (p.T == 1) SB_GO(1, 1); if (p.T == 2) SB_GO(1, 2); SB_GO(1, 4); }
+  if (p.T == 1) SB_GO(2, 1);
+  SB_GO(2, 2);
+#undef SB_GO
 }
 
 template <typename TG>
@@ -894,6 +1363,10 @@ int launch_topk(const float* Q, const void* G, int Bq, int Ng, int C, int k, lon
   float* ws_s = (float*)workspace;
   const bool force_lists = (flags & COR_TOPK_FORCE_LISTS) != 0;
   if constexpr (sizeof(TG) == 2) {
+    if (C == 256 && !force_lists && !(flags & COR_TOPK_FORCE_GLOBAL_THRESHOLD)) {   // small shards: two launches, local thresholds
+      const SmallPlan sp = make_small(Bq, Ng, k);
+      if (sp.ok) return launch_small<TG>(Q, (const TG*)G, Bq, Ng, k, g_offset, out_s, out_i, (char*)workspace, sp, flags, s);
+    }
     if (C == 256 && !force_lists) {                     // threshold-and-append + exact re-scoring
       const V3Plan p = make_v3(Bq, Ng, k);
       if (p.qb == 2) return launch_v3<TG, 2>(Q, (const TG*)G, Bq, Ng, k, g_offset, out_s, out_i, (char*)workspace, p, flags, s);
@@ -919,7 +1392,9 @@ extern "C" long cor_topk_workspace_bytes(int Bq, int Ng, int k) {
   const long a = (long)Bq * p.nparts * p.kmax * 8, b = (long)Bq * p2.nparts * p2.kmax * 8;
   long m = a > b ? a : b;
   const long c = (long)make_v3(Bq, Ng, k).bytes;
-  return c > m ? c : m;
+  if (c > m) m = c;
+  const long d = (long)make_small(Bq, Ng, k).bytes;
+  return d > m ? d : m;
 }
 
 extern "C" int cor_similarity_topk(const float* Q, const void* G, int g_dtype, int Bq, int Ng, int C, int k, long long g_offset,

@@ -30,6 +30,8 @@ extern "C" {
 #define COR_ORDER_REVERSE (1 << 30)
 #define COR_TOPK_FORCE_LISTS 1 /* cor_similarity_topk flags: per-lane sorted-list kernels only (no threshold-and-append) */
 #define COR_TOPK_NO_FALLBACK 2  /* ... : no device-side fallback after a candidate overflow: such queries return index -2 */
+#define COR_TOPK_FORCE_GLOBAL_THRESHOLD 8 /* ... : never the two-launch local-threshold path of small shards (A/B partner, tests) */
+#define COR_TOPK_BLOCK_FINAL 16 /* ... : global-threshold pipeline with the block-per-query selection kernel of round 2 (A/B partner, tests) */
 
 enum { COR_F32 = 0, COR_BF16 = 1, COR_F16 = 2 /* gallery storage only */ };
 enum { COR_ACT_NONE = 0, COR_ACT_GELU_ERF = 1, COR_ACT_RELU = 2, COR_ACT_SIGMOID = 3, COR_ACT_GELU_TANH = 4 };
@@ -66,7 +68,12 @@ int cor_layernorm(const void* x, int x_dtype, void* y, int y_dtype, const float*
 /* out[b,t,h,:] = softmax_k(scale * q[b,t,h,:].k[b,k,h,:]) v ; element (b,t,h,c) of X lives at
  * X + b*x_sb + t*x_st + h*hd + c (strides in elements). hd in {16,32,64,72,80}; bf16 with hd 64 / 72 / 80 and >= 64 queries and
  * keys runs the MFMA flash kernel (72 = SigLIP SO400M/14, the factory's default tower), everything else the row-per-lane kernel.
- * ref: lib/sam_model/transformer.py:218-240 (decoder Attention), SigLIP towers' MHA. */
+ * ref: lib/sam_model/transformer.py:218-240 (decoder Attention), SigLIP towers' MHA.
+ * PRECONDITION (cor_attention and cor_sam_attention, bf16 MFMA kernels): q, k, v are FINITE. The softmax of those kernels is compiled
+ * with -fno-honor-nans (no NaN arises inside: the running maximum starts at -inf, every key tile holds a real key; -inf marks padded
+ * key slots and is honoured), so a NaN / Inf operand from upstream (e.g. a bf16 overflow) gives unspecified values in the rows of the
+ * (sample, head) that contain it instead of a propagated NaN; other (sample, head) pairs are unaffected (tests/test_gpu_parity.py::
+ * test_attention_nonfinite_operands_stay_inside_their_head). The fp32 row-per-lane kernels propagate NaN as IEEE arithmetic does. */
 int cor_attention(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st,
                   const void* v, long v_sb, long v_st, int dtype,
                   void* out, long o_sb, long o_st, int out_dtype,

@@ -762,7 +762,7 @@ def test_full_depth_bf16_vs_reference_golden_with_counts(pooling):
     inp = make_inputs(int(g["seed_inputs"]), q=(1, 3, 1024, 1024), s=(1, 3, 384, 384), text=("tokens", 1, 64, 512), mask=("mask", 1, 384))
     kw = dict(query_image_inputs=inp["q"].to(DEV), support_image_inputs=inp["s"].to(DEV), change_text_inputs=inp["text"].to(DEV),
               support_mask_inputs=inp["mask"].to(DEV))
-    _, _, _, aux32 = model.forward_with_aux(**kw, multimask_output=True)                      # fp32 exact mode: pinned to the golden
+    _, _, feat32, aux32 = model.forward_with_aux(**kw, multimask_output=True)                 # fp32 exact mode: pinned to the golden
     flips_total, px_total = 0, 0
     for mm in (1, 0):
         with torch.autocast("cuda", dtype=torch.bfloat16):                                  # like vailder.py:416
@@ -814,6 +814,55 @@ def test_full_depth_bf16_vs_reference_golden_with_counts(pooling):
     _note(name=f"full_depth_bf16_retrieval_{pooling}", recall_at_1_vs_fp32_oracle=rec1, planted_is_top1=bool(ri[0, 0] == where),
           top10_index_mismatches=mism, of=10, max_score_diff=float((s_b.cpu() - rs).abs().max()))
     assert ri[0, 0] == where and rec1 == 1.0
+    # ---- (c) north_star's "bit-exact top-k indices", end to end in the mode that can deliver it: the exact-fp32
+    # HIP forward's feature through cor_similarity_topk  vs  the REFERENCE's fp32 feature through the CPU chain top-k, same gallery
+    # like with like: fp32 gallery holding the stored bf16 values (exact fp32 fmaf chain on the device) vs the chain oracle
+    s_x, i_x = retrieval.GalleryShard(rows.float().to(DEV), 0).search(feat32[:, 0].float(), 10)
+    rs, ri = oret.similarity_topk(q_ref, rows.float(), 10, exact_chain=True)
+    mism32 = int((i_x.cpu() != ri).sum())
+    _note(name=f"full_depth_fp32_mode_retrieval_{pooling}", fp32_mode_topk_index_mismatches_vs_reference=mism32, of=10,
+          max_score_diff=float((s_x.cpu() - rs).abs().max()), feature_max_abs_err=float((feat32[:, 0].float().cpu() - q_ref).abs().max()))
+    assert mism32 == 0, (i_x.cpu().tolist(), ri.tolist())
+
+
+def test_attention_nonfinite_operands_stay_inside_their_head():
+    """include/cor_amd.h: finite q / k / v are a PRECONDITION of the bf16 MFMA attention kernels (their softmax is compiled with
+    -fno-honor-nans). What a violation may cost is bounded: a NaN / Inf in one (sample, head) leaves every OTHER
+    (sample, head) bit-identical to the clean run - plain MHA (flash_fwd<0>), windowed SAM attention (win_attn: the poisoned window's
+    head only) and global SAM attention (flash_global_pipe)."""
+    ops, _ = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, H, T, hd = 2, 3, 256, 64
+    d = H * hd
+    qkv = torch.randn((B * T, 3 * d), generator=g, device=DEV).to(BF16)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    clean = ops.attention(q, k, v, B, H, T, T, hd, 0.125)
+    bad = qkv.clone()
+    bad[5, 1 * hd + 7] = float("nan")                    # q of sample 0, head 1
+    bad[T + 9, d + 2 * hd + 3] = float("inf")            # k of sample 1, head 2
+    out = ops.attention(bad[:, :d], bad[:, d:2 * d], bad[:, 2 * d:], B, H, T, T, hd, 0.125)
+    keep = torch.ones((B, H), dtype=torch.bool)
+    keep[0, 1] = keep[1, 2] = False
+    for b in range(B):
+        for h in range(H):
+            if keep[b, h]:
+                assert torch.equal(out[b * T:(b + 1) * T, h * hd:(h + 1) * hd], clean[b * T:(b + 1) * T, h * hd:(h + 1) * hd]), (b, h)
+    # SAM attention, windowed (grid 28 = 2x2 windows) and global (grid 64)
+    for grid, window in ((28, 14), (64, 0)):
+        S = window or grid
+        n = grid * grid
+        x = torch.randn((B * n, 3 * d), generator=g, device=DEV).to(BF16)
+        pad = torch.randn((3 * d,), generator=g, device=DEV).to(BF16)
+        rh = torch.randn((2 * S - 1, hd), generator=g, device=DEV) * 0.3
+        rw = torch.randn((2 * S - 1, hd), generator=g, device=DEV) * 0.3
+        clean = ops.sam_attention(x, pad, rh, rw, B, H, grid, window)
+        xb = x.clone()
+        xb[n + 3 * grid + 2, 2 * d + 0 * hd + 11] = float("nan")     # v of sample 1, head 0, token (3, 2): window (0, 0) when windowed
+        out = ops.sam_attention(xb, pad, rh, rw, B, H, grid, window)
+        same = (out == clean).view(B, grid, grid, H, hd)
+        assert bool(same[0].all()) and bool(same[1, :, :, 1:].all()), (grid, window)
+        if window:
+            assert bool(same[1, 14:].all()) and bool(same[1, :, 14:].all())                  # the other three windows of that head too
 
 
 def test_batch32_bf16_vs_fp32_exact_mode_anchored_to_the_golden():
@@ -938,6 +987,82 @@ def test_eight_way_sharded_search_equals_the_unsharded_oracle(Bq, Ng, gdt, name)
     mism = int((mi != ri).sum()); bits = int((ms.view(torch.int32) != rs.view(torch.int32)).sum())
     _note(name=f"eight_way_sharded_search_{Bq}x{Ng}_{gdt}", what=name, index_mismatches=mism, score_bit_mismatches=bits, entries=int(ri.numel()))
     assert mism == 0 and bits == 0, (mism, bits)
+
+
+@pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 12500, 10, BF16), (256, 12500, 10, torch.float16), (32, 100000, 10, BF16), (64, 33000, 10, BF16),
+                                         (300, 20011, 32, BF16), (33, 5000, 12, torch.float16), (1, 300, 5, BF16), (40, 255, 32, BF16)])
+def test_similarity_small_shard_path_equals_the_global_threshold_path(Bq, Ng, k, gdt):
+    """The two-launch local-threshold path of small shards (sim_block_scan + sim_final_wave: the 8-GPU shard shapes and few-query
+    searches) against the five-launch global-threshold pipeline (COR_TOPK_FORCE_GLOBAL_THRESHOLD) and the CPU chain oracle: scores and
+    indices BITWISE, duplicate rows across slice borders included; run twice (the candidate order inside the lists depends on LDS
+    atomics, the answer must not)."""
+    ops, _ = _ops()
+    from cor_amd import _native as nat
+    rng = np.random.default_rng(Bq * 7 + Ng)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Bq, 256), dtype=np.float32)), dim=-1)
+    G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Ng, 256), dtype=np.float32)), dim=-1).to(gdt)
+    if Ng > 1100:
+        G[1024] = G[1023]; G[511] = G[512]; G[Ng - 1] = G[17]; G[Ng - 300] = G[17]
+    G[5] = G[3]
+    Qd, Gd = Q.to(DEV), G.to(DEV)
+    s1, i1 = ops.similarity_topk(Qd, Gd, k, g_offset=7)
+    s1b, i1b = ops.similarity_topk(Qd, Gd, k, g_offset=7)
+    s2, i2 = ops.similarity_topk(Qd, Gd, k, g_offset=7, flags=nat.TOPK_FORCE_GLOBAL_THRESHOLD)
+    assert torch.equal(i1, i1b) and torch.equal(s1.view(torch.int32), s1b.view(torch.int32))
+    assert torch.equal(i1, i2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
+    rs, ri = oret.similarity_topk_chain(Q.to(gdt).float(), G.float(), k)
+    kk = min(k, Ng)
+    assert torch.equal(i1[:, :kk].cpu() - 7, ri) and torch.equal(s1[:, :kk].cpu().view(torch.int32), rs.view(torch.int32))
+    _note(name=f"topk_small_path_{Bq}x{Ng}_k{k}_{gdt}", index_mismatches=0, score_bit_mismatches=0, entries=int(ri.numel()))
+
+
+@pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 125000, 10, torch.float16), (300, 70001, 5, BF16), (64, 40000, 10, BF16), (512, 3000, 16, BF16)])
+def test_similarity_wave_selection_equals_the_block_selection_kernel(Bq, Ng, k, gdt):
+    """Global-threshold pipeline: the round-4 form (SAMPLE pass converts the queries itself, ballot-counting sim_tau, one-wave-per-query
+    selection with LDS-DMA row staging) against the round-2 form (sim_prep launch + block-per-query sim_final, COR_TOPK_BLOCK_FINAL):
+    scores and indices bitwise, and both bitwise against the chain oracle (test_similarity_topk covers the default path)."""
+    ops, _ = _ops()
+    from cor_amd import _native as nat
+    rng = np.random.default_rng(Bq * 3 + Ng)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Bq, 256), dtype=np.float32)), dim=-1)
+    G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Ng, 256), dtype=np.float32)), dim=-1).to(gdt)
+    G[5] = G[3]; G[Ng - 1] = G[17]
+    f = nat.TOPK_FORCE_GLOBAL_THRESHOLD
+    s1, i1 = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, flags=f)
+    s2, i2 = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, flags=f | nat.TOPK_BLOCK_FINAL)
+    assert torch.equal(i1, i2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
+    rs, ri = oret.similarity_topk_chain(Q.to(gdt).float(), G.float(), k)
+    assert torch.equal(i1.cpu(), ri) and torch.equal(s1.cpu().view(torch.int32), rs.view(torch.int32))
+
+
+def test_similarity_small_shard_path_overflow_falls_back_on_the_device():
+    """Degenerate small shard (every row identical): every slice list overflows; sim_final_wave flags the query and ranks the whole
+    shard with the exact chain inside the same wave (COR_TOPK_NO_FALLBACK exposes the raw marker -2)."""
+    ops, _ = _ops()
+    from cor_amd import _native as nat
+    rng = np.random.default_rng(6)
+    Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((40, 256), dtype=np.float32)), dim=-1)
+    row = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((1, 256), dtype=np.float32)), dim=-1)
+    G = row.repeat(9000, 1).to(BF16)
+    s, i = ops.similarity_topk(Q.to(DEV), G.to(DEV), 10)
+    assert torch.equal(i.cpu(), torch.arange(10).repeat(40, 1)), i[:2]
+    _, raw = ops.similarity_topk(Q.to(DEV), G.to(DEV), 10, flags=nat.TOPK_NO_FALLBACK)
+    assert (raw == -2).all()
+    G2 = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((9000, 256), dtype=np.float32)), dim=-1)
+    G2[2000:6000] = torch.nn.functional.normalize(Q[0:1] + 0.05 * row, dim=-1)
+    G2 = G2.to(BF16)
+    s2, i2 = ops.similarity_topk(Q.to(DEV), G2.to(DEV), 10)
+    _, raw2 = ops.similarity_topk(Q.to(DEV), G2.to(DEV), 10, flags=nat.TOPK_NO_FALLBACK)
+    flagged = (raw2 == -2).all(dim=1).cpu()
+    # LOCAL thresholds: a slice made of identical rows overflows its list for EVERY query (all its rows tie at the slice's own k-th
+    # best), not only for the query they are close to - a run of >= 64 identical rows inside one 256..1024-row slice costs every query
+    # the exact in-wave fallback (slow, exact, no host round trip); the global-threshold pipeline flags query 0 only
+    assert bool(flagged[0]), flagged
+    _, raw3 = ops.similarity_topk(Q.to(DEV), G2.to(DEV), 10, flags=nat.TOPK_NO_FALLBACK | nat.TOPK_FORCE_GLOBAL_THRESHOLD)
+    flagged3 = (raw3 == -2).all(dim=1).cpu()
+    assert bool(flagged3[0]) and int(flagged3.sum()) < 40, flagged3
+    rs, ri = oret.similarity_topk_chain(Q.to(BF16).float(), G2.float(), 10, margin=1e-3)
+    assert torch.equal(i2.cpu(), ri) and torch.equal(s2.cpu().view(torch.int32), rs.view(torch.int32))
 
 
 def test_similarity_topk_lists_fallback_kernels():
@@ -1239,8 +1364,9 @@ def test_fp32_mode_per_stage_vs_fp64_oracle():
     there, against 2e-5 on the N(0,1) goldens)? Every stage is measured twice: HIP fp32 vs oracle fp64, and oracle fp32 (torch
     CPU) vs oracle fp64 - the second column is what fp32 arithmetic itself costs at that stage. The decoder stages are run
     ISOLATED (both fed the fp64 oracle's embedding and feature rounded to fp32), so an amplifying stage shows up as such and
-    not as inherited error. Assertion: HIP fp32 is within 4x of torch fp32's own distance to fp64 at every stage (plus a floor
-    of 2e-6 of the stage's scale); the table goes to the parity report."""
+    not as inherited error. Assertions: HIP fp32 is within 4x of torch fp32's own distance to fp64 at every isolated stage and at
+    the two encoder outputs, and within 8x at every END-TO-END decoder stage (plus a floor of 2e-6 of the stage's scale), so a
+    regression of the encoder's fp32 path cannot hide behind the decoder's conditioning; the table goes to the parity report."""
     from cor_amd import utils, engine
     from cor_amd.lib.build_model import build_model_with_query_support_feat
     model = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskAdapterPooling")
@@ -1295,7 +1421,7 @@ def test_fp32_mode_per_stage_vs_fp64_oracle():
         return float((a - b).abs().max()), float(b.abs().max())
 
     stages = ["sam_embedding", "support_feature", "tokens_l0", "keys_l0", "tokens_l1", "keys_l1", "hs", "upscaled1", "hyper", "iou", "masks_all"]
-    worst = []
+    worst, worst_e2e = [], []
     for st in stages:
         for kind, hip, o32, truth in (("end_to_end", hip_full, o32_full, o64), ("isolated", hip_iso, o32_iso, o64_iso)):
             if st not in hip or st not in truth:
@@ -1307,6 +1433,10 @@ def test_fp32_mode_per_stage_vs_fp64_oracle():
             if kind == "isolated" or st in ("sam_embedding", "support_feature"):
                 if eh > 4.0 * eo + 2e-6 * scale:
                     worst.append(rec)
+            elif eh > 8.0 * eo + 2e-6 * scale:
+                # end-to-end decoder stages inherit the encoder's error times the decoder's gain (3e4 per unit with this init): the
+                # conditioning argument is a BOUND here, not a comment - measured worst 6.7x (tokens_l0), 5.9x (iou)
+                worst_e2e.append(rec)
     # the end-to-end logits: inherited embedding error times the decoder's own amplification (reported, bounded loosely)
     eh, scale = dist(hip_full["masks_all"], o64["masks_all"])
     eo, _ = dist(o32_full["masks_all"], o64["masks_all"])
@@ -1315,6 +1445,7 @@ def test_fp32_mode_per_stage_vs_fp64_oracle():
     _note(name="fp32_stage_table_amplification", hip_logit_err=eh, oracle32_logit_err=eo, logit_scale=scale,
           hip_logit_err_per_unit_embedding_err=amp_h, oracle32_logit_err_per_unit_embedding_err=amp_o)
     assert not worst, f"HIP fp32 is more than 4x further from fp64 than torch fp32 at: {worst}"
+    assert not worst_e2e, f"end to end, HIP fp32 is more than 8x further from fp64 than torch fp32 at: {worst_e2e}"
 
 
 def test_gallery_builder_and_checkpoint_loader(tmp_path):
@@ -1607,4 +1738,25 @@ def test_bench_contract_smoke(tmp_path):
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     rec = d["recall"]
     assert rec["queries"] == 4 and rec["oracle_recall_at_1_planted"] == 1.0 and rec["recall_at_1"] == 1.0 and rec["max_pairwise_cos"] < 0.9
+    # exact-fp32 HIP pipeline end to end vs the CPU oracle end to end: top-k INDICES identical (north_star)
+    assert rec["fp32_mode_topk_entries"] == 30 and rec["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0, rec
+    assert d["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0 and d["cpu_oracle_recall_at_1"] == 1.0
+    assert "clock" in d and d["config"]["multimask_output"] is True
+
+
+def test_bench_gpus2_gloo_rehearsal_launches_two_ranks_by_itself(tmp_path):
+    """`python bench.py --gpus 2 --backend gloo` ALONE (no torchrun around it, no WORLD_SIZE): the launcher starts two ranks that share
+    this box's one GPU, the gallery is sharded two ways, queries are all-gathered, lists gathered and merged; the line says n_gpus 2
+    and carries the `rccl` record (backend gloo here: a rehearsal of the code path, not of RCCL)."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "2", "--gallery", "5000",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+    rc = d["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo" and rc["calls"] == 2 and rc["collective_ms"] > 0 and rc["search_ms"] > 0
 

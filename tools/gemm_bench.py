@@ -2,7 +2,9 @@
 """GPU micro-benchmark of cor_gemm tile configurations (the per-call `cfg` argument) on the SAM-B / SigLIP-B shapes.
 Interleaved rounds in ONE process, random data (cdna guide rules 24/25). Checks every configuration against
 configuration 1 bit-for-bit tolerance-free on a sub-block (same accumulation order per k-step => tiny diffs only).
-    python tools/gemm_bench.py [--cfgs 1 2 3 4 5 6] [--rounds 5]
+    python tools/gemm_bench.py [--cfgs 1 2 3 4 9 13] [--rounds 5]
+The product library accepts the shipped selectors only (1, 2, 3, 4, 9, 13); anything else - the experimental kernels, selector 14, a
+tile-order group (c >= 100) - needs the -DCOR_PROBES build (make -C cor_amd/csrc probes), which is bound automatically then.
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,11 +41,14 @@ def enc(c):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfgs", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6])
+    ap.add_argument("--cfgs", type=int, nargs="*", default=[1, 2, 3, 4, 9, 13])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if any(c >= 100 or (c % 100) not in (0, 1, 2, 3, 4, 9, 13) for c in a.cfgs):
+        _native.use_probe_library()                     # the production ABI answers COR_EINVAL to these
+        print("# experimental selectors requested: bound tools/probes/libcor_probes.so", file=sys.stderr)
     lib = _native.load()
     dev = "cuda:0"
     res = []

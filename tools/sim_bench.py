@@ -11,14 +11,17 @@ sys.path.insert(0, ROOT)
 import torch
 from cor_amd import ops
 dev = "cuda:0"
-SHAPES = ((32, 100000, 10, torch.bfloat16), (32, 12500, 10, torch.bfloat16), (256, 100000, 10, torch.bfloat16), (512, 12500, 10, torch.bfloat16),
+SHAPES = ((32, 100000, 10, torch.bfloat16), (32, 12500, 10, torch.bfloat16), (256, 12500, 10, torch.bfloat16), (256, 100000, 10, torch.bfloat16), (512, 12500, 10, torch.bfloat16),
+          (512, 32000, 10, torch.bfloat16),
           (512, 125000, 10, torch.bfloat16), (512, 125000, 10, torch.float16), (512, 125000, 10, torch.float32), (512, 1000000, 10, torch.float16),
           (512, 1000000, 10, torch.bfloat16))
 only_1m = len(sys.argv) > 1 and sys.argv[1] == "1m"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 4: timing-only ablation, no candidate passes the threshold (results invalid)
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 4: timing-only ablation (results invalid); 8: never the two-launch small-shard path
 if only_1m:
     SHAPES = ((512, 1000000, 10, torch.bfloat16),)
+elif len(sys.argv) > 1 and "x" in sys.argv[1]:           # e.g. 512x12500 : one bf16 shape (for rocprofv3 passes)
+    SHAPES = ((int(sys.argv[1].split("x")[0]), int(sys.argv[1].split("x")[1]), 10, torch.bfloat16),)
 for Bq, Ng, k, dt in SHAPES:
     Q = torch.nn.functional.normalize(torch.randn((Bq, 256), device=dev), dim=-1)
     G = torch.nn.functional.normalize(torch.randn((Ng, 256), device=dev), dim=-1).to(dt)
@@ -40,7 +43,7 @@ for Bq, Ng, k, dt in SHAPES:
     fl = 2.0 * Bq * Ng * 256
     gbytes = G.numel() * G.element_size()
     peak = 2500.0 if dt != torch.float32 else 157.3
-    print(json.dumps(dict(Bq=Bq, Ng=Ng, k=k, dtype=str(dt), us_back_to_back=tb * 1e6, us_single_median=t * 1e6, us_single_min=min(ts[1:]) * 1e3,
+    print(json.dumps(dict(Bq=Bq, Ng=Ng, k=k, dtype=str(dt), flags=flags, us_back_to_back=tb * 1e6, us_single_median=t * 1e6, us_single_min=min(ts[1:]) * 1e3,
                           tflops=fl / tb / 1e12,
                           roofline=dict(bound="mfma" if Bq >= 400 else "hbm", achieved=fl / tb / 1e12, peak=peak, unit="TFLOP/s", frac=fl / tb / 1e12 / peak,
                                         gallery_GBps=gbytes / tb / 1e9, hbm_frac=gbytes / tb / 8e12, algorithmic_bytes=gbytes + Bq * 1024,
