@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcor_amd.so")
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4
 EINVAL, ENOSUPPORT = -1, -2
-TOPK_FORCE_LISTS, TOPK_NO_FALLBACK, TOPK_FORCE_GLOBAL_THRESHOLD, TOPK_BLOCK_FINAL = 1, 2, 8, 16
+TOPK_FORCE_LISTS, TOPK_NO_FALLBACK, TOPK_FORCE_GLOBAL_THRESHOLD, TOPK_WAVE_FINAL = 1, 2, 8, 16
 ORDER_REVERSE = 1 << 30    # cor_gemm cfg / cor_layernorm act / cor_sam_attention variant: walk the work from the last item to the first
 KERNEL_ROWLANE, KERNEL_FEWQ, KERNEL_FLASH_MFMA, KERNEL_FLASH_PIPELINED, KERNEL_WINDOW_BLOCK = 1, 2, 3, 4, 5
 import numpy as _np

@@ -320,9 +320,7 @@ struct ScanArgs {
   int Bq, Ng, nqg, nsplit, tiles_per_split;
   int ntiles;                      // 64-row super-tiles this launch walks (SAMPLE: sample super-tiles; APPEND: all of them)
   int tile_stride;                 // super-tiles between consecutive walked super-tiles (SAMPLE: >= 1; APPEND: 1)
-  const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep, or the SAMPLE pass itself)
-  const float* q_f32;              // SAMPLE only, or null: convert the fp32 queries here, publish the image (blocks of slice 0) and clear the flags
-  uint4* qimg_w; int* flags;
+  const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep)
   float* pmax; int ngroups;        // SAMPLE: pmax[q * ngroups + split * 2 + h]
   float tau_add;                   // 0; timing-only ablation (COR_TOPK_DEBUG_NOCAND): +1e30 = no candidate ever passes
   const float* tau; int* cnt; float* rec_s; int* rec_g; int cap;     // APPEND: record i of stream (q, slice, half): 16 scores + first row
@@ -364,25 +362,12 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     // K-fragments from the fragment-major image sim_prep wrote (query block, K-step, lane) x 16 B: 1 KiB per wave-instruction,
     // 16 of them per query block (reading the fp32 rows cost every CU 512 KiB of L2 traffic per launch: ~7 us)
     const uint4* qimg = a.qimg + ((long)(q0 / 32 + qb) * 16) * 64 + lane;
-    if (SAMPLE && a.q_f32) {
-      // no sim_prep launch: this pass converts the fp32 rows itself (a 5.6-us launch + boundary saved for ~3.5 us more L2 traffic
-      // here), and the blocks of gallery slice 0 publish the fragment-major image the APPEND pass reads
-      const float* qrow = a.q_f32 + (long)min(q0 + qb * 32 + r, a.Bq - 1) * C;
-      uint4* wimg = a.qimg_w + ((long)(q0 / 32 + qb) * 16) * 64 + lane;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        qf[qb][c] = active ? q_frag16<TG>(qrow, c, h) : make_uint4(0, 0, 0, 0);
-        if (active && split == 0) wimg[c * 64] = qf[qb][c];
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
-    }
+    for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
     const int q = min(q0 + qb * 32 + r, a.Bq - 1);
     tau[qb] = SAMPLE ? 0.f : a.tau[q] + a.tau_add;
     gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
-  if (SAMPLE && a.q_f32 && blockIdx.x == 0 && tid == 0) a.flags[0] = 0;     // per-call overflow flag (sim_prep's other duty)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
   const unsigned wbase = (unsigned)wave * 1024u;       // this wave's first slot (bytes) per 8-KiB pass
   int st_row[4], st_src[4];                            // a super-tile = 64 rows x 512 B = four 8-KiB passes of the block
@@ -626,6 +611,32 @@ __device__ void brute_force_topk(const TG* __restrict__ G, int Ng, const float* 
   }
 }
 
+// chain score of a gallery row staged in LDS (32 chunks of 16 B; chunk c sits in slot c ^ x): the order of oracle/c/sim_chain.c
+template <typename TG>
+__device__ __forceinline__ float chain_score_lds(const char* row, int x, const float* qs) {
+  float acc = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < 32; ++c) {
+    const uint4 v = *(const uint4*)(row + ((c ^ x) << 4));
+    const f32x4 qa = *(const f32x4*)(qs + 8 * c), qb = *(const f32x4*)(qs + 8 * c + 4);
+    float g[8];
+    if (__is_same(TG, bf16_t)) {
+      g[0] = __uint_as_float(v.x << 16); g[1] = __uint_as_float(v.x & 0xffff0000u); g[2] = __uint_as_float(v.y << 16); g[3] = __uint_as_float(v.y & 0xffff0000u);
+      g[4] = __uint_as_float(v.z << 16); g[5] = __uint_as_float(v.z & 0xffff0000u); g[6] = __uint_as_float(v.w << 16); g[7] = __uint_as_float(v.w & 0xffff0000u);
+    } else {
+      const f16x8 hv = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = (float)hv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = fmaf(g[i], qa[i], acc);
+      acc = fmaf(g[4 + i], qb[i], acc);
+    }
+  }
+  return acc;
+}
+
 // D. exact top-k of one query's candidates. LDS: cs/ci [FS_MAX] | sl_s/sl_i [SL_MAX] | qs[256] | hist[256].
 template <typename TG>
 __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, const TG* __restrict__ G, const float* rec_s, const int* rec_g,
@@ -648,14 +659,21 @@ __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, co
   // 1. the private stream lists hold whole 16-score columns (records): keep the scores >= tau_q (the admission threshold of
   // the scan, delta already subtracted) and compact them into LDS. Register e of lane half h is row g0 + (e&3) + 8 (e>>2) + 4 h.
   const float tq = tau[q];
-  auto take = [&](const f32x4 (&v)[4], int g0, int h4) {
+  auto take = [&](const f32x4 (&v)[4], int g0, int h4) {            // ONE returning LDS atomic per record (round 2: one per passing score,
+    int np = 0;                                                       // up to 16 dependent LDS round trips per record)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) np += (v[g][i] >= tq && v[g][i] > -INFINITY) ? 1 : 0;
+    if (np == 0) return;
+    int p = atomicAdd(&total, np);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (v[g][i] >= tq && v[g][i] > -INFINITY) {
-          const int p = atomicAdd(&total, 1);
           if (p < FS_MAX) { cs[p] = v[g][i]; ci[p] = g0 + i + 8 * g + h4; }
+          ++p;
         }
   };
   for (int st = tid; st < nstreams; st += 256) {
@@ -745,7 +763,28 @@ __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, co
   }
   const int m = nsl;
   // 4. exact re-scoring: the fmaf chain of oracle/c/sim_chain.c (chunk c = 0..31 of 8: k = 8c+i then 8c+4+i, i = 0..3)
-  for (int j = tid; j < m; j += 256) sl_s[j] = chain_score<TG>(G, sl_i[j], qs);
+  // The rows arrive by LDS-DMA in the candidate buffer (dead from here: 64 rows x 512 B per round, wave w stages rows 16 w ..; slot
+  // (lane & 31) of row j is fed from source chunk (lane & 31) ^ (j & 31)), all in flight at once; then thread j runs the chain over
+  // its row. Round 2 read the rows from global memory inside the chain: 32 loads, four in flight = eight dependent round trips.
+  {
+    const int lane_ = tid & 63, wave_ = tid >> 6;
+    const unsigned ldsR = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)cs)) + (unsigned)wave_ * 8192u;
+    for (int base = 0; base < m; base += 64) {
+      const int nr = min(64, m - base);
+      __syncthreads();                                   // the candidate buffer / the previous round's rows are no longer read
+#pragma unroll 1
+      for (int i = 0; i < 8; ++i) {
+        const int jj = wave_ * 16 + 2 * i + (lane_ >> 5);
+        if (wave_ * 16 + 2 * i < nr) {                   // wave-uniform
+          const long idx = sl_i[base + min(jj, nr - 1)];
+          glds16(G + idx * 256 + (((lane_ & 31) ^ (jj & 31)) << 3), __builtin_amdgcn_readfirstlane(ldsR + 1024u * i));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid < nr) sl_s[base + tid] = chain_score_lds<TG>((const char*)cs + tid * 512, tid & 31, qs);
+    }
+  }
   __syncthreads();
   // 5. rank by (chain score desc, index asc); entries beyond the short list (Ng < k) are (-inf, -1)
   for (int j = tid; j < m; j += 256) {
@@ -815,6 +854,7 @@ inline int device_cus() { return cor_device_cus(); }
 // ranking 32-64 queries: measured choice, see DESIGN 3.4.
 constexpr int SB_NC = 4096;                            // candidates per query held in LDS by sim_final_wave (32 KiB)
 constexpr int SB_SL = 64;                              // short list (one entry per lane)
+constexpr int SB_MAXSL = 192;                          // slices per query the wave final can gather (make_small keeps nslices below)
 
 struct SmallPlan {
   bool ok;
@@ -826,16 +866,18 @@ inline SmallPlan make_small(int Bq, int Ng, int k) {
   p.qb = Bq > 32 ? 2 : 1;
   p.nqg = cdiv(Bq, 32 * p.qb);
   const int tmax = p.qb == 2 ? 2 : 4;                  // accumulators: 16 * T * QB <= 64 registers
-  int target = device_cus() / p.nqg;                   // about one block per CU
-  if (target < 1) target = 1;
-  int t = cdiv(cdiv(Ng, target), 256);
+  // A block's time is a LATENCY chain (~11 us: query conversion, two DMA round trips, threshold, append), not throughput, and the
+  // selection kernel's time grows with the candidates (~12 per slice and query): the fewest, largest slices that still fit one
+  // round of blocks. Shapes that need a second round (512 x 32 000: 55 us here against 48 on the global-threshold pipeline) or more
+  // than 32 slices per query stay on the global-threshold pipeline.
+  int t = cdiv(Ng, 256);
   p.T = t <= 1 ? 1 : (t == 2 ? 2 : tmax);              // instantiated: 1, 2, (4 for QB = 1)
   if (p.T > tmax) p.T = tmax;
   p.nslices = cdiv(Ng, 256 * p.T);
-  p.cap = k <= 12 ? 64 : 160;                          // entries per (query, slice) list: ~k + 2 expected
+  p.cap = k <= 12 ? 128 : 256;                         // entries per (query, slice) list: ~k + 2 expected; a sparse last slice: all its rows
   p.xcd_map = p.nslices >= 8 ? 1 : 0;                  // blocks that share a gallery slice share an XCD (its L2)
   p.grid = p.nqg * (p.xcd_map ? ((p.nslices + 7) & ~7) : p.nslices);
-  p.ok = (long)p.nslices * (k + 8) * 13 / 10 <= 3072 && p.grid <= 65535 * 8;
+  p.ok = p.nslices <= 32 && p.nqg * p.nslices <= device_cus() && (long)p.nslices * (k + 8) * 13 / 10 <= 3072 && p.nslices <= SB_MAXSL;
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
   p.off_flags = take(16);
@@ -850,8 +892,14 @@ inline SmallPlan make_small(int Bq, int Ng, int k) {
 template <typename TG, int QB, int T>
 __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict__ Q, const TG* __restrict__ G, int Bq, int Ng, int k, int nqg,
                                                          int nslices, int xcd_map, int cap, int* __restrict__ cnt, uint2* __restrict__ cand,
-                                                         int* __restrict__ flags) {
+                                                         int* __restrict__ flags, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef COR_PROBES
+  unsigned long long ts_[10]; int nts_ = 0;
+#define SB_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[nts_++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SB_STAMP() do { } while (0)
+#endif
   constexpr int QPB = 32 * QB, ZB = QB * 16 * 64 * 16, TPQ = 512 / QPB, FPT = 256 / TPQ, VPT = 64 / TPQ, CS = QPB + 1;
   constexpr int RPW = 32 * T, RPB = 8 * RPW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
@@ -861,9 +909,16 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
   if (slice >= nslices) return;                        // padding blocks of the XCD mapping (whole block, before any barrier)
   if (blockIdx.x == 0 && tid == 0) flags[0] = 0;       // per-call overflow flag (the final kernel runs behind this one)
   const int q0 = qg * QPB;
-  const long w0 = (long)slice * RPB + wave * RPW;      // this wave's first gallery row
+  // A short (last) slice spreads its rows over as many waves as possible - tl = ceil(rows / 256) tiles per wave instead of T - so that
+  // the 32 row classes below stay populated: with fewer than k non-empty classes the threshold is -inf and EVERY row of the slice is
+  // a candidate, which the list (cap >= 128 / 256) only holds when such a slice has at most 64 (k <= 12) / 224 rows. (Seen at
+  // 32 x 12 500: 212 rows in two waves, 8 classes, 212 candidates per query and slice, every query on the brute-force fallback.)
+  const long slice0 = (long)slice * RPB;
+  const int rows_here = (int)(Ng - slice0 < RPB ? Ng - slice0 : RPB);
+  const int tl = (rows_here + 255) / 256;              // <= T
+  const long w0 = slice0 + wave * (32 * tl);           // this wave's first gallery row
   int ntw = (int)((Ng - w0 + 31) / 32);                // 32-row tiles of this wave inside the shard (wave-uniform)
-  ntw = ntw < 0 ? 0 : (ntw > T ? T : ntw);
+  ntw = ntw < 0 ? 0 : (ntw > tl ? tl : ntw);
   const int nsteps = 2 * ntw;                          // K-half tiles
 
   char* Z = smem;                                      // query image (prologue), then class maxima / thresholds / list counters
@@ -881,6 +936,7 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
       glds16(G + gr * 256 + ((sl ^ (row & 15)) + 16 * p) * 8, __builtin_amdgcn_readfirstlane(ldsA + p * 8192 + 1024 * i));
     }
   };
+  SB_STAMP();                                          // 0: start
   if (nsteps > 0) issue(0);
   if (nsteps > 1) issue(1);
 
@@ -909,6 +965,12 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
 #pragma unroll
     for (int c = 0; c < 16; ++c) qf[qb][c] = ((const uint4*)Z)[(qb * 16 + c) * 64 + lane];
   __syncthreads();                                     // Z is free from here on
+  SB_STAMP();                                          // 1: queries converted, fragments in registers
+  float* cmx = (float*)Z;                              // [32 classes][CS]: class = (wave * 2 + h) * 2 + j ; padded stride: conflict-free both ways
+  float* thr = cmx + 32 * CS;                          // [QPB]
+  int* lcnt = (int*)(thr + QPB);                       // [QPB]
+  float* dlt = (float*)(lcnt + QPB);                   // [QPB] delta_q
+  if (pp == 0) dlt[qq] = SIM_DELTA * fmaxf(1.f, sqrtf(nrm2));
 
   f32x16 acc[QB][T];
 #pragma unroll
@@ -950,109 +1012,105 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
       }
     }
   }
-  // rows beyond the shard (clamped duplicates, absent tiles) never count; class maxima: register e over the wave's tiles, 16 -> 4
-  float* cmx = (float*)Z;                              // [64 classes][CS]: class = (wave * 2 + h) * 4 + j ; padded stride: conflict-free both ways
-  float* thr = cmx + 64 * CS;                          // [QPB]
-  int* lcnt = (int*)(thr + QPB);                       // [QPB]
+  SB_STAMP();                                          // 2: scan done
+  // rows beyond the shard (clamped duplicates, absent tiles) never count: only the last slice has any
+  if (w0 + RPW > Ng || tl < T) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (t >= ntw || w0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h >= Ng) acc[qb][t][e] = -INFINITY;
+  }
+  // class maxima: 32 disjoint row classes per query and block = (wave, lane half, register parity); their k-th largest is a lower
+  // bound of the query's k-th best score in the shard (k classes each hold a row at least that good)
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    float cm[16];
+    float c0 = -INFINITY, c1 = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float m = -INFINITY;
+    for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const long row = w0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (t >= ntw || row >= Ng) acc[qb][t][e] = -INFINITY;
-        m = fmaxf(m, acc[qb][t][e]);
-      }
-      cm[e] = m;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      cmx[((wave * 2 + h) * 4 + j) * CS + qb * 32 + r] = fmaxf(fmaxf(cm[j], cm[j + 4]), fmaxf(cm[j + 8], cm[j + 12]));
+      for (int e = 0; e < 16; e += 2) { c0 = fmaxf(c0, acc[qb][t][e]); c1 = fmaxf(c1, acc[qb][t][e + 1]); }
+    cmx[((wave * 2 + h) * 2 + 0) * CS + qb * 32 + r] = c0;
+    cmx[((wave * 2 + h) * 2 + 1) * CS + qb * 32 + r] = c1;
   }
   __syncthreads();
-  // tau_q = (k-th largest of the 64 class maxima, floored to 16 key bits) - delta_q: counting binary search, TPQ lanes per query
-  {
-    unsigned keys[VPT];
+  SB_STAMP();                                          // 3: class maxima exchanged
+  // tau_q = k-th largest of the 32 class maxima: lane <-> query, a 32-element bitonic network in registers (the K-fragments are dead),
+  // 240 compare-exchanges for all 64 queries at once. (First forms: TPQ lanes per query with ds_bpermute count reductions, ~3 us;
+  // one scalar counting search per query, 130 cycles per step of a serial v_cmp -> s_bcnt1 -> s_cselect chain: 8 us.)
+  if (wave == 0 && lane < QPB) {
+    float v[32];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) keys[i] = f2key(cmx[(pp * VPT + i) * CS + qq]) >> 16;
-    unsigned lo = 0x007Fu, hi = 0x10000u;             // 0x007F = key prefix of -inf: "fewer than k classes hold a row"
-#pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-      const unsigned mid = (lo + hi) >> 1;
-      int c = 0;
+    for (int c = 0; c < 32; ++c) v[c] = cmx[c * CS + lane];
 #pragma unroll
-      for (int i = 0; i < VPT; ++i) c += keys[i] >= mid ? 1 : 0;
+    for (int kk = 2; kk <= 32; kk <<= 1)
 #pragma unroll
-      for (int o = 1; o < TPQ; o <<= 1) c += __shfl_xor(c, o, 64);
-      if (c >= k) lo = mid; else hi = mid;
-    }
-    if (pp == 0) {
-      const float tau = lo == 0x007Fu ? -INFINITY : key2f_floor(lo << 16);
-      thr[qq] = tau - SIM_DELTA * fmaxf(1.f, sqrtf(nrm2));
-      lcnt[qq] = 0;
-    }
+      for (int j = kk >> 1; j > 0; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int l = i ^ j;
+          if (l > i) {
+            const float x = v[i], y = v[l];
+            if ((i & kk) == 0) { v[i] = fmaxf(x, y); v[l] = fminf(x, y); }      // descending
+            else               { v[i] = fminf(x, y); v[l] = fmaxf(x, y); }
+          }
+        }
+    float kth = v[0];
+#pragma unroll
+    for (int c = 1; c < 32; ++c) kth = (c == k - 1) ? v[c] : kth;
+    // (fewer than k classes hold a row: -inf, every real row is a candidate; the floor keeps masked -inf scores out with ONE compare)
+    thr[lane] = fmaxf(kth - dlt[lane], -3.0e38f);
+    lcnt[lane] = 0;
   }
   __syncthreads();
-  // append the registers that pass to the block's per-query lists (the A buffers are free: every wave is past its scan)
+  SB_STAMP();                                          // 4: thresholds
+  // append the registers that pass to the block's per-query lists (the A buffers are free: every wave is past its scan). One LDS
+  // atomic per lane and query block reserves room for the lane's passing registers; the stores are EXEC-masked, not branched: hipcc
+  // turned `if (pass) store` into 64 taken branches per wave (9 000 cycles of a 45 000-cycle block), so each register is one
+  // v_cmp -> s_and_saveexec -> ds_write2_b32 (score, row) -> address += 8 -> restore exec, in inline asm.
   uint2* lst = (uint2*)(smem + ZB);                    // [QPB][cap]
+  const unsigned lds_lst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(smem + ZB));
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int ql = qb * 32 + r;
-    const float tq = thr[ql];
-    const bool live = q0 + ql < Bq;
+    float tq = (q0 + ql < Bq) ? thr[ql] : INFINITY;                // padding queries never append
+    int np = 0;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      float tmax = max3f(acc[qb][t][0], acc[qb][t][1], acc[qb][t][2]);
+    for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, acc[qb][t][e], acc[qb][t][e + 1]);
-      tmax = fmaxf(tmax, acc[qb][t][15]);
-      if (__builtin_amdgcn_ballot_w64(live && tmax >= tq && tmax > -INFINITY) == 0) continue;
+      for (int e = 0; e < 16; ++e) np += acc[qb][t][e] >= tq ? 1 : 0;
+    const int pos0 = np > 0 ? atomicAdd(&lcnt[ql], np) : 0;
+    if (pos0 + np > cap) tq = INFINITY;                            // the list is full: this lane stores nothing; cnt > cap flags the query
+    unsigned addr = lds_lst + (unsigned)(ql * cap + pos0) * 8u;
+    const unsigned rowb = (unsigned)w0 + 4u * h;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float v = acc[qb][t][e];
-        if (live && v >= tq && v > -INFINITY) {
-          const int slot = atomicAdd(&lcnt[ql], 1);
-          if (slot < cap) lst[ql * cap + slot] = make_uint2(__float_as_uint(v), (unsigned)(w0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h));
-        }
+        const unsigned rowv = rowb + (unsigned)(32 * t + (e & 3) + 8 * (e >> 2));
+        unsigned long long sv;
+        asm volatile("v_cmp_ge_f32 vcc, %2, %3\n\ts_and_saveexec_b64 %1, vcc\n\tds_write2_b32 %0, %2, %4 offset1:1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, %1"
+                     : "+v"(addr), "=&s"(sv) : "v"(acc[qb][t][e]), "v"(tq), "v"(rowv) : "vcc", "memory");
       }
-    }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm stores are invisible to hipcc's counter bookkeeping
   __syncthreads();
+  SB_STAMP();                                          // 5: lists filled
   if (q0 + qq < Bq) {
     const int n_raw = lcnt[qq], n = min(n_raw, cap);
     const long li = (long)(q0 + qq) * nslices + slice;
     if (pp == 0) cnt[li] = n_raw;                      // > cap: sim_final_wave sees the overflow
     for (int j = pp; j < n; j += TPQ) cand[li * cap + j] = lst[qq * cap + j];
   }
-}
-
-// chain score of a gallery row staged in LDS (32 chunks of 16 B; chunk c sits in slot c ^ x): the order of oracle/c/sim_chain.c
-template <typename TG>
-__device__ __forceinline__ float chain_score_lds(const char* row, int x, const float* qs) {
-  float acc = 0.f;
-#pragma unroll 4
-  for (int c = 0; c < 32; ++c) {
-    const uint4 v = *(const uint4*)(row + ((c ^ x) << 4));
-    const f32x4 qa = *(const f32x4*)(qs + 8 * c), qb = *(const f32x4*)(qs + 8 * c + 4);
-    float g[8];
-    if (__is_same(TG, bf16_t)) {
-      g[0] = __uint_as_float(v.x << 16); g[1] = __uint_as_float(v.x & 0xffff0000u); g[2] = __uint_as_float(v.y << 16); g[3] = __uint_as_float(v.y & 0xffff0000u);
-      g[4] = __uint_as_float(v.z << 16); g[5] = __uint_as_float(v.z & 0xffff0000u); g[6] = __uint_as_float(v.w << 16); g[7] = __uint_as_float(v.w & 0xffff0000u);
-    } else {
-      const f16x8 hv = __builtin_bit_cast(f16x8, v);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] = (float)hv[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc = fmaf(g[i], qa[i], acc);
-      acc = fmaf(g[4 + i], qb[i], acc);
-    }
+#ifdef COR_PROBES
+  SB_STAMP();                                          // 6: written out
+  if (stamps && lane == 0) {
+    for (int i = 0; i < nts_; ++i) stamps[((long)blockIdx.x * 8 + wave) * 8 + i] = ts_[i];
   }
-  return acc;
+#endif
+#undef SB_STAMP
 }
 
 // ONE WAVE per query: gather the candidates, select, re-score exactly, rank. Two gather front ends: RECORDS = false: the
@@ -1088,73 +1146,119 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
     if (lane == 0) total = 0;
     __syncthreads();
     const float tq = tau[q];
-    auto take = [&](const f32x4 (&v)[4], int g0, int h4) {
+    auto take = [&](const f32x4 (&v)[4], int g0, int h4) {          // one LDS atomic per record (not per score), then predicated stores
+      int np = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) np += (v[g][i] >= tq && v[g][i] > -INFINITY) ? 1 : 0;
+      if (np == 0) return;
+      int pos = atomicAdd(&total, np);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (v[g][i] >= tq && v[g][i] > -INFINITY) {
-            const int pos = atomicAdd(&total, 1);
             if (pos < SB_NC) { cs[pos] = v[g][i]; ci[pos] = g0 + i + 8 * g + h4; }
+            ++pos;
           }
     };
-    for (int st = lane; st < nslices; st += 64) {
-      const long rec0 = ((long)q * nslices + st) * cap;
-      const f32x4* src = (const f32x4*)(rec_s + rec0 * 16);
-      const f32x4 v0[4] = {src[0], src[1], src[2], src[3]};
-      const int g00 = rec_g[rec0];
-      const int c = cnt[(long)q * nslices + st];
-      if (c > cap) ovf = true;
-      const int nrec = min(c, cap), h4 = 4 * (st & 1);
-      if (nrec > 0) take(v0, g00, h4);
-      for (int j = 1; j < nrec; ++j) {
-        const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 16);
-        const f32x4 vj[4] = {sj[0], sj[1], sj[2], sj[3]};
-        take(vj, rec_g[rec0 + j], h4);
+    // the loads of up to 8 streams per lane (512 streams) are issued together: one global round trip, not one per 64 streams
+    constexpr int RS = 8;
+    for (int sb = 0; sb < nslices; sb += 64 * RS) {
+      f32x4 v0[RS][4]; int g00[RS], cc[RS];
+#pragma unroll
+      for (int u = 0; u < RS; ++u) {
+        const int st = sb + 64 * u + lane;
+        const long rec0 = ((long)q * nslices + (st < nslices ? st : 0)) * cap;
+        const f32x4* src = (const f32x4*)(rec_s + rec0 * 16);
+        v0[u][0] = src[0]; v0[u][1] = src[1]; v0[u][2] = src[2]; v0[u][3] = src[3];
+        g00[u] = rec_g[rec0];
+        cc[u] = st < nslices ? cnt[(long)q * nslices + st] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < RS; ++u) {
+        const int st = sb + 64 * u + lane;
+        if (cc[u] > cap) ovf = true;
+        const int nrec = min(cc[u], cap), h4 = 4 * (st & 1);
+        if (nrec > 0) take(v0[u], g00[u], h4);
+        if (nrec > 1) {
+          const long rec0 = ((long)q * nslices + st) * cap;
+          for (int j = 1; j < nrec; ++j) {
+            const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 16);
+            const f32x4 vj[4] = {sj[0], sj[1], sj[2], sj[3]};
+            take(vj, rec_g[rec0 + j], h4);
+          }
+        }
       }
     }
     __syncthreads();
     n = total;
   }
-  // 1. gather: lane <-> slice, exclusive prefix of the list lengths, then entry j of every slice per round
-  for (int s0 = 0; !RECORDS && s0 < nslices; s0 += 64) {
-    const int s = s0 + lane;
-    int c = s < nslices ? cnt[(long)q * nslices + s] : 0;
-    if (c > cap) { ovf = true; c = cap; }
-    int incl = c;
+  // 1. gather. Pass 1: lane <-> slice, list lengths and their exclusive prefix (soff). Pass 2: lane <-> ENTRY of the flattened
+  // list (its slice by a binary search over soff): four independent loads per lane and round, so the whole gather is about one
+  // global round trip (a first form walked entry j of every slice per round: one dependent round trip per entry, ~12 us)
+  if (!RECORDS) {
+    __shared__ int soff[SB_MAXSL + 1];
+    for (int s0 = 0; s0 < nslices; s0 += 64) {
+      const int s = s0 + lane;
+      int c = s < nslices ? cnt[(long)q * nslices + s] : 0;
+      if (c > cap) { ovf = true; c = cap; }
+      int incl = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    const int off = n + incl - c;
-    int cmax = c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
-    const uint2* src = cand + ((long)q * nslices + (s < nslices ? s : 0)) * cap;
-    for (int j = 0; j < cmax; ++j) {
-      if (j < c && off + j < SB_NC) { const uint2 e = src[j]; cs[off + j] = __uint_as_float(e.x); ci[off + j] = (int)e.y; }
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      if (s < nslices) soff[s] = n + incl - c;
+      n += __builtin_amdgcn_readlane(incl, 63);
     }
-    n += __builtin_amdgcn_readlane(incl, 63);
+    if (lane == 0) soff[nslices] = n;
+    __syncthreads();
+    const uint2* qc = cand + (long)q * nslices * cap;
+    const int nn = min(n, SB_NC);
+    for (int i0 = 0; i0 < nn; i0 += 256) {
+      uint2 e[4]; int idx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        idx[u] = i0 + 64 * u + lane;
+        const int i = min(idx[u], nn - 1);
+        int lo = 0, hi = nslices;                          // largest s with soff[s] <= i (empty slices repeat an offset: the search skips them)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (soff[mid] <= i) lo = mid; else hi = mid; }
+        e[u] = qc[(long)lo * cap + (i - soff[lo])];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (idx[u] < nn) { cs[idx[u]] = __uint_as_float(e[u].x); ci[idx[u]] = (int)e[u].y; }
+    }
+    __syncthreads();
   }
   n = __builtin_amdgcn_readfirstlane(n);
   if (__builtin_amdgcn_ballot_w64(ovf) != 0 || n > SB_NC) ovf = true; else ovf = false;
   __syncthreads();
   const float delta = SIM_DELTA * fmaxf(1.f, sqrtf(sl_s[0]));
   __syncthreads();
-  // 2. T_lo <= T = k-th best MFMA score: counting binary search over the top 20 key bits (n <= k: every candidate is in)
+  // 2. T_lo <= T = k-th best MFMA score: counting binary search over the top 16 key bits (n <= k: every candidate is in)
   float T = -INFINITY;
   int m = 0;
   if (!ovf) {
     if (n > k) {
-      unsigned lo = 0x007FFu, hi = 0x100000u;
+      // keys of the first 512 candidates in registers (8 per lane; typical n: a few hundred), the rest re-read from LDS; every
+      // step of the search is compares + ballots + scalar bit counts (no cross-lane reduction, no LDS round trip)
+      unsigned kr[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kr[j] = lane + 64 * j < n ? f2key(cs[lane + 64 * j]) >> 16 : 0u;
+      unsigned lo = 0x007Fu, hi = 0x10000u;
 #pragma unroll 1
-      for (int it = 0; it < 20; ++it) {
+      for (int it = 0; it < 16; ++it) {
         const unsigned mid = (lo + hi) >> 1;
         int c = 0;
-        for (int i = lane; i < n; i += 64) c += (f2key(cs[i]) >> 12) >= mid ? 1 : 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        for (int j = 0; j < 8; ++j) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(kr[j] >= mid));
+        for (int i0 = 512; i0 < n; i0 += 64)
+          c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i0 + lane < n && (f2key(cs[min(i0 + lane, n - 1)]) >> 16) >= mid));
         if (c >= k) lo = mid; else hi = mid;
       }
-      T = lo == 0x007FFu ? -INFINITY : key2f_floor(lo << 12);
+      // T_lo = the smallest float whose key starts with the k-th best score's 16 bits (within 2^-7 relative below T): the short list
+      // cut T_lo - delta admits a superset of what T - delta would; exactness is unaffected
+      T = lo == 0x007Fu ? -INFINITY : key2f_floor(lo << 16);
     }
     // 3. short list: MFMA score >= T - delta (ballot compaction; order irrelevant: the ranking below is total)
     const float cut = T - delta;
@@ -1297,16 +1401,13 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
   float* rec_s = (float*)(w + p.off_recs); int* rec_g = (int*)(w + p.off_recg);
   uint4* qimg = (uint4*)(w + p.off_img);
-  // 0. queries -> gallery dtype, fragment-major; clears the per-call overflow flags. Only when no SAMPLE pass runs (tiny shards on
-  // the forced global-threshold path) or for the round-2 selection kernel: otherwise the SAMPLE pass does it (one launch fewer)
-  const bool use_prep = p.ngroups == 0 || (flags & COR_TOPK_BLOCK_FINAL);
-  if (use_prep) {
-    hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
-    COR_CHECK_LAUNCH();
-  }
+  // 0. queries -> gallery dtype, fragment-major; clears the per-call overflow flags. (Folding this conversion into the SAMPLE pass -
+  // every wave converting its own 64 fp32 rows, the blocks of slice 0 publishing the image - was built and measured in round 4: the
+  // SAMPLE pass grew from 8-10 to 21.6 us at 125k rows and from 22.7 to 37 us at 1M, against the 5.6-us launch it replaced: reverted.)
+  hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
+  COR_CHECK_LAUNCH();
   ScanArgs a{};
   a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg; a.qimg = qimg;
-  a.q_f32 = use_prep ? nullptr : Q; a.qimg_w = qimg; a.flags = dflags;
   if (p.ngroups > 0) {                                  // A. group maxima of the strided sample
     a.nsplit = p.s_nsplit; a.tiles_per_split = p.s_tiles_per_split; a.ntiles = p.s_tiles; a.tile_stride = p.s_stride;
     a.pmax = pmax; a.ngroups = p.ngroups;
@@ -1321,13 +1422,14 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   a.tau = tau; a.cnt = cnt; a.rec_s = rec_s; a.rec_g = rec_g; a.cap = p.cap; a.tau_add = (flags & 4) ? 1e30f : 0.f;
   hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, G, a);
   COR_CHECK_LAUNCH();
-  // D. exact selection: one wave per query (COR_TOPK_BLOCK_FINAL: the round-2 block-per-query kernel, kept as the A/B partner)
-  if (flags & COR_TOPK_BLOCK_FINAL)
-    hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, rec_s, rec_g, tau, cnt, p.nstreams, p.cap, Ng, k, g_offset, out_s, out_i,
-                       dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
-  else
+  // D. exact selection: one 256-thread block per query. (COR_TOPK_WAVE_FINAL: the one-wave-per-query kernel of the small-shard path fed
+  // from the records - measured 52-59 us against 25 here: 512 streams are eight dependent gather rounds for one wave. A/B partner only.)
+  if (flags & COR_TOPK_WAVE_FINAL)
     hipLaunchKernelGGL((sim_final_wave<TG, true>), dim3(Bq), dim3(64), 0, s, Q, G, cnt, nullptr, rec_s, rec_g, tau, p.nstreams, p.cap, Ng, k, g_offset,
                        out_s, out_i, dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
+  else
+    hipLaunchKernelGGL((sim_final<TG>), dim3(Bq), dim3(256), fs_lds, s, Q, G, rec_s, rec_g, tau, cnt, p.nstreams, p.cap, Ng, k, g_offset, out_s, out_i,
+                       dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);
   COR_CHECK_LAUNCH();
   return 0;                                             // (an overflowed query was ranked exactly inside sim_final: no second launch)
 }
@@ -1340,7 +1442,12 @@ int launch_small_t(const float* Q, const TG* G, int Bq, int Ng, int k, long long
   cor_max_dyn_lds((const void*)sim_block_scan<TG, QB, T>, (int)lds, once);
   int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
   uint2* cand = (uint2*)(w + p.off_cand);
-  hipLaunchKernelGGL((sim_block_scan<TG, QB, T>), dim3(p.grid), dim3(512), lds, s, Q, G, Bq, Ng, k, p.nqg, p.nslices, p.xcd_map, p.cap, cnt, cand, dflags);
+#ifdef COR_PROBES
+  unsigned long long* stamps = (flags & 32) ? (unsigned long long*)(w + cor_topk_workspace_bytes(Bq, Ng, k)) : nullptr;   // tools/sim_stamps.py: 2 MiB behind the workspace
+#else
+  unsigned long long* stamps = nullptr;
+#endif
+  hipLaunchKernelGGL((sim_block_scan<TG, QB, T>), dim3(p.grid), dim3(512), lds, s, Q, G, Bq, Ng, k, p.nqg, p.nslices, p.xcd_map, p.cap, cnt, cand, dflags, stamps);
   COR_CHECK_LAUNCH();
   hipLaunchKernelGGL((sim_final_wave<TG, false>), dim3(Bq), dim3(64), 0, s, Q, G, cnt, cand, nullptr, nullptr, nullptr, p.nslices, p.cap, Ng, k, g_offset,
                      out_s, out_i, dflags, ovf_q, (flags & COR_TOPK_NO_FALLBACK) ? 1 : 0);

@@ -31,7 +31,7 @@ extern "C" {
 #define COR_TOPK_FORCE_LISTS 1 /* cor_similarity_topk flags: per-lane sorted-list kernels only (no threshold-and-append) */
 #define COR_TOPK_NO_FALLBACK 2  /* ... : no device-side fallback after a candidate overflow: such queries return index -2 */
 #define COR_TOPK_FORCE_GLOBAL_THRESHOLD 8 /* ... : never the two-launch local-threshold path of small shards (A/B partner, tests) */
-#define COR_TOPK_BLOCK_FINAL 16 /* ... : global-threshold pipeline with the block-per-query selection kernel of round 2 (A/B partner, tests) */
+#define COR_TOPK_WAVE_FINAL 16 /* ... : global-threshold pipeline with the one-wave-per-query selection kernel fed from the records (slower A/B partner, tests) */
 
 enum { COR_F32 = 0, COR_BF16 = 1, COR_F16 = 2 /* gallery storage only */ };
 enum { COR_ACT_NONE = 0, COR_ACT_GELU_ERF = 1, COR_ACT_RELU = 2, COR_ACT_SIGMOID = 3, COR_ACT_GELU_TANH = 4 };

@@ -989,8 +989,9 @@ def test_eight_way_sharded_search_equals_the_unsharded_oracle(Bq, Ng, gdt, name)
     assert mism == 0 and bits == 0, (mism, bits)
 
 
-@pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 12500, 10, BF16), (256, 12500, 10, torch.float16), (32, 100000, 10, BF16), (64, 33000, 10, BF16),
-                                         (300, 20011, 32, BF16), (33, 5000, 12, torch.float16), (1, 300, 5, BF16), (40, 255, 32, BF16)])
+@pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 12500, 10, BF16), (256, 12500, 10, torch.float16), (32, 12500, 10, BF16), (8, 12500, 10, BF16),
+                                         (32, 30000, 10, BF16), (64, 8193, 32, BF16), (300, 5000, 32, BF16), (33, 5000, 12, torch.float16),
+                                         (1, 300, 5, BF16), (40, 255, 32, BF16), (512, 16384, 10, torch.float16)])
 def test_similarity_small_shard_path_equals_the_global_threshold_path(Bq, Ng, k, gdt):
     """The two-launch local-threshold path of small shards (sim_block_scan + sim_final_wave: the 8-GPU shard shapes and few-query
     searches) against the five-launch global-threshold pipeline (COR_TOPK_FORCE_GLOBAL_THRESHOLD) and the CPU chain oracle: scores and
@@ -1008,6 +1009,10 @@ def test_similarity_small_shard_path_equals_the_global_threshold_path(Bq, Ng, k,
     s1, i1 = ops.similarity_topk(Qd, Gd, k, g_offset=7)
     s1b, i1b = ops.similarity_topk(Qd, Gd, k, g_offset=7)
     s2, i2 = ops.similarity_topk(Qd, Gd, k, g_offset=7, flags=nat.TOPK_FORCE_GLOBAL_THRESHOLD)
+    # no query may take the brute-force fallback on a benign gallery: a sparse LAST slice (32 x 12 500: 212 rows) once left fewer
+    # than k row classes populated, its threshold at -inf and every query on the fallback - exact, 25x slower
+    _, raw = ops.similarity_topk(Qd, Gd, k, g_offset=7, flags=nat.TOPK_NO_FALLBACK)
+    assert int((raw == -2).sum()) == 0
     assert torch.equal(i1, i1b) and torch.equal(s1.view(torch.int32), s1b.view(torch.int32))
     assert torch.equal(i1, i2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
     rs, ri = oret.similarity_topk_chain(Q.to(gdt).float(), G.float(), k)
@@ -1019,7 +1024,7 @@ def test_similarity_small_shard_path_equals_the_global_threshold_path(Bq, Ng, k,
 @pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 125000, 10, torch.float16), (300, 70001, 5, BF16), (64, 40000, 10, BF16), (512, 3000, 16, BF16)])
 def test_similarity_wave_selection_equals_the_block_selection_kernel(Bq, Ng, k, gdt):
     """Global-threshold pipeline: the round-4 form (SAMPLE pass converts the queries itself, ballot-counting sim_tau, one-wave-per-query
-    selection with LDS-DMA row staging) against the round-2 form (sim_prep launch + block-per-query sim_final, COR_TOPK_BLOCK_FINAL):
+    selection with LDS-DMA row staging) against the round-2 form (sim_prep launch + block-per-query sim_final, COR_TOPK_WAVE_FINAL):
     scores and indices bitwise, and both bitwise against the chain oracle (test_similarity_topk covers the default path)."""
     ops, _ = _ops()
     from cor_amd import _native as nat
@@ -1029,7 +1034,7 @@ def test_similarity_wave_selection_equals_the_block_selection_kernel(Bq, Ng, k, 
     G[5] = G[3]; G[Ng - 1] = G[17]
     f = nat.TOPK_FORCE_GLOBAL_THRESHOLD
     s1, i1 = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, flags=f)
-    s2, i2 = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, flags=f | nat.TOPK_BLOCK_FINAL)
+    s2, i2 = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, flags=f | nat.TOPK_WAVE_FINAL)
     assert torch.equal(i1, i2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
     rs, ri = oret.similarity_topk_chain(Q.to(gdt).float(), G.float(), k)
     assert torch.equal(i1.cpu(), ri) and torch.equal(s1.cpu().view(torch.int32), rs.view(torch.int32))
