@@ -140,7 +140,7 @@ def launch_check(args):
 
 
 NB_CPU = 3          # bounded CPU sample: 3 triplets ~ 14 s on 16 cores (the contract asks for 10-30 s)
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # written by tools/pmc_traffic.py for THIS build
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # written by tools/pmc_traffic.py for THIS build
 
 
 def gemm_source_id():
