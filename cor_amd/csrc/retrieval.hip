@@ -877,7 +877,9 @@ inline SmallPlan make_small(int Bq, int Ng, int k) {
   p.cap = k <= 12 ? 128 : 256;                         // entries per (query, slice) list: ~k + 2 expected; a sparse last slice: all its rows
   p.xcd_map = p.nslices >= 8 ? 1 : 0;                  // blocks that share a gallery slice share an XCD (its L2)
   p.grid = p.nqg * (p.xcd_map ? ((p.nslices + 7) & ~7) : p.nslices);
-  p.ok = p.nslices <= 32 && p.nqg * p.nslices <= device_cus() && (long)p.nslices * (k + 8) * 13 / 10 <= 3072 && p.nslices <= SB_MAXSL;
+  // k <= 16: the threshold is the k-th largest of 32 class maxima; near k = 32 it is their MINIMUM, a weak and volatile bound (one query
+  // of 300 overflowed a 256-entry list at 300 x 5 000, k = 32): such searches keep the global threshold
+  p.ok = k <= 16 && p.nslices <= 32 && p.nqg * p.nslices <= device_cus() && (long)p.nslices * (k + 8) * 13 / 10 <= 3072 && p.nslices <= SB_MAXSL;
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
   p.off_flags = take(16);
@@ -909,16 +911,17 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
   if (slice >= nslices) return;                        // padding blocks of the XCD mapping (whole block, before any barrier)
   if (blockIdx.x == 0 && tid == 0) flags[0] = 0;       // per-call overflow flag (the final kernel runs behind this one)
   const int q0 = qg * QPB;
-  // A short (last) slice spreads its rows over as many waves as possible - tl = ceil(rows / 256) tiles per wave instead of T - so that
-  // the 32 row classes below stay populated: with fewer than k non-empty classes the threshold is -inf and EVERY row of the slice is
-  // a candidate, which the list (cap >= 128 / 256) only holds when such a slice has at most 64 (k <= 12) / 224 rows. (Seen at
-  // 32 x 12 500: 212 rows in two waves, 8 classes, 212 candidates per query and slice, every query on the brute-force fallback.)
+  // A short (last) slice spreads its rows EVENLY over the eight waves (floor(rows / 8) each, the remainder one apiece, instead of 32 T), so
+  // that the 32 row classes below stay populated: a wave with >= 8 rows fills its four classes, hence every slice with >= 64 rows has
+  // all 32 (k <= 32 of them are needed), and a slice with fewer rows may well declare every row a candidate - the list holds >= 128.
+  // (Seen at 32 x 12 500: 212 rows in two waves, 8 classes < k, threshold -inf, 212 candidates per query, every query on the brute-force
+  // fallback; and at 300 x 5 000, k = 32: 392 rows in seven waves, 28 classes, the same.)
   const long slice0 = (long)slice * RPB;
   const int rows_here = (int)(Ng - slice0 < RPB ? Ng - slice0 : RPB);
-  const int tl = (rows_here + 255) / 256;              // <= T
-  const long w0 = slice0 + wave * (32 * tl);           // this wave's first gallery row
-  int ntw = (int)((Ng - w0 + 31) / 32);                // 32-row tiles of this wave inside the shard (wave-uniform)
-  ntw = ntw < 0 ? 0 : (ntw > tl ? tl : ntw);
+  const int rpw = rows_here >> 3, rem = rows_here & 7; // floor(rows / 8) per wave, the first `rem` waves one more: >= 8 each from 64 rows up
+  const long w0 = slice0 + wave * rpw + (wave < rem ? wave : rem);          // this wave's first gallery row
+  const int own = rpw + (wave < rem ? 1 : 0);          // rows this wave owns (wave-uniform): 32 T in a full slice
+  const int ntw = (own + 31) >> 5;                     // 32-row tiles this wave scans (<= T)
   const int nsteps = 2 * ntw;                          // K-half tiles
 
   char* Z = smem;                                      // query image (prologue), then class maxima / thresholds / list counters
@@ -1013,15 +1016,15 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
     }
   }
   SB_STAMP();                                          // 2: scan done
-  // rows beyond the shard (clamped duplicates, absent tiles) never count: only the last slice has any
-  if (w0 + RPW > Ng || tl < T) {
+  // rows beyond the wave's share (the next wave's rows, clamped duplicates, absent tiles) never count: only a short slice has any
+  if (own < RPW) {                                     // (a full slice: own == 32 T)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          if (t >= ntw || w0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h >= Ng) acc[qb][t][e] = -INFINITY;
+          if (32 * t + (e & 3) + 8 * (e >> 2) + 4 * h >= own) acc[qb][t][e] = -INFINITY;
   }
   // class maxima: 32 disjoint row classes per query and block = (wave, lane half, register parity); their k-th largest is a lower
   // bound of the query's k-th best score in the shard (k classes each hold a row at least that good)

@@ -990,7 +990,7 @@ def test_eight_way_sharded_search_equals_the_unsharded_oracle(Bq, Ng, gdt, name)
 
 
 @pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 12500, 10, BF16), (256, 12500, 10, torch.float16), (32, 12500, 10, BF16), (8, 12500, 10, BF16),
-                                         (32, 30000, 10, BF16), (64, 8193, 32, BF16), (300, 5000, 32, BF16), (33, 5000, 12, torch.float16),
+                                         (32, 30000, 10, BF16), (64, 8193, 16, BF16), (300, 5000, 16, BF16), (300, 5000, 32, BF16), (33, 5000, 12, torch.float16),
                                          (1, 300, 5, BF16), (40, 255, 32, BF16), (512, 16384, 10, torch.float16)])
 def test_similarity_small_shard_path_equals_the_global_threshold_path(Bq, Ng, k, gdt):
     """The two-launch local-threshold path of small shards (sim_block_scan + sim_final_wave: the 8-GPU shard shapes and few-query
