@@ -229,13 +229,16 @@ int cor_resample_cols_u8(const unsigned char* in, float* out_f32, unsigned char*
  * missing entries (Ng < k) come back as score -inf, index -1. workspace >= cor_topk_workspace_bytes(Bq,Ng,k).
  * The reference has no gallery/top-k code; the definition follows utils/loss_func.py:84 (cosine of unit vectors).
  * Scores are DEFINED as the fp32 fmaf chain of oracle/c/sim_chain.c (16-bit rows widened exactly), for every gallery dtype: the
- * result is bit-identical to that CPU chain, scores and indices. fp32 shards run the chain kernel. 16-bit shards of >= 32768
- * rows run threshold-and-append on the matrix cores (a strided sample pass bounds each query's k-th best score, the full MFMA
- * pass appends the rare score records above the bound, the final pass re-scores a short list with the exact chain); if a
- * query's candidate list overflows (pathological score distributions) its block falls back to an exact brute-force chain
- * pass ON THE DEVICE (no host round trip). `flags` (per call, no process-global state): 0 = default;
- * COR_TOPK_FORCE_LISTS = per-lane sorted-list kernels only; COR_TOPK_NO_FALLBACK = report an overflow as index -2 in every
- * slot of the query instead of falling back (tests). */
+ * result is bit-identical to that CPU chain, scores and indices. fp32 shards run the chain kernel. 16-bit shards (C = 256) scan on the
+ * matrix cores and re-score a short list with the exact chain: SMALL shards (<= 32 slices of 256..1024 rows per query in one round of
+ * blocks, k <= 16: the 8-GPU shard shapes, 256..512 queries x 12.5k rows) in TWO launches with block-local thresholds (sim_block_scan:
+ * every block bounds its queries' k-th best score from the maxima of 32 disjoint row classes of its own slice and appends what passes;
+ * sim_final_wave: one wave per query selects, re-scores, ranks); everything else by threshold-and-append with a GLOBAL threshold (a strided
+ * sample pass bounds each query's k-th best score, the full MFMA pass appends the rare score records above the bound, the final pass
+ * re-scores the short list). If a query's candidate list overflows (pathological score distributions, e.g. hundreds of identical rows)
+ * it is ranked by an exact brute-force chain pass ON THE DEVICE (no host round trip). `flags` (per call, no process-global state):
+ * 0 = default; COR_TOPK_FORCE_LISTS = per-lane sorted-list kernels only; COR_TOPK_NO_FALLBACK = report an overflow as index -2 in every
+ * slot of the query instead of falling back (tests); COR_TOPK_FORCE_GLOBAL_THRESHOLD / COR_TOPK_WAVE_FINAL = A/B partners (tests). */
 long cor_topk_workspace_bytes(int Bq, int Ng, int k);
 int cor_similarity_topk(const float* Q, const void* G, int g_dtype, int Bq, int Ng, int C, int k, long long g_offset,
                         float* out_scores, long long* out_idx, void* workspace, int flags, void* stream);
