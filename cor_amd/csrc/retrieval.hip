@@ -1406,7 +1406,10 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   uint4* qimg = (uint4*)(w + p.off_img);
   // 0. queries -> gallery dtype, fragment-major; clears the per-call overflow flags. (Folding this conversion into the SAMPLE pass -
   // every wave converting its own 64 fp32 rows, the blocks of slice 0 publishing the image - was built and measured in round 4: the
-  // SAMPLE pass grew from 8-10 to 21.6 us at 125k rows and from 22.7 to 37 us at 1M, against the 5.6-us launch it replaced: reverted.)
+  // SAMPLE pass grew from 8-10 to 21.6 us at 125k rows and from 22.7 to 37 us at 1M, against the 5.6-us launch it replaced: reverted. A
+  // second form - COALESCED 1-KiB row loads, transposed into fragments through the wave's 16 KiB of the idle gallery ring - costs the
+  // SAMPLE pass +4.5 us (every block still pulls 512 KiB of fp32 rows through its CU's L2 port against 256 KiB of the image) and the whole
+  // call +3..+8 us at 125k / 1M rows: reverted too. The 5-us launch is the cheapest way to convert 512 queries once.)
   hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
   COR_CHECK_LAUNCH();
   ScanArgs a{};
