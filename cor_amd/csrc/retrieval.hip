@@ -1132,6 +1132,8 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
   __shared__ float sl_s[SB_SL];
   __shared__ int sl_i[SB_SL];
   const int q = blockIdx.x, lane = threadIdx.x;
+  // (the first 64 list lengths are requested together with the query row: one global round trip instead of two)
+  const int c_first = (!RECORDS && lane < nslices) ? cnt[(long)q * nslices + lane] : 0;
   {
     const f32x4 v = *(const f32x4*)(Q + (long)q * 256 + 4 * lane);
     float n2 = 0.f;
@@ -1205,7 +1207,7 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
     __shared__ int soff[SB_MAXSL + 1];
     for (int s0 = 0; s0 < nslices; s0 += 64) {
       const int s = s0 + lane;
-      int c = s < nslices ? cnt[(long)q * nslices + s] : 0;
+      int c = s0 == 0 ? c_first : (s < nslices ? cnt[(long)q * nslices + s] : 0);
       if (c > cap) { ovf = true; c = cap; }
       int incl = c;
 #pragma unroll
