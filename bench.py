@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
     ap.add_argument("--multimask", type=int, default=1, help="multimask_output of the forward (1: three masks + IoU arg-max select, as in rounds 1-3; "
                     "0: the reference's shipped config/vaild_config/vaild_config.yaml:13 - skips cor_iou_select's 3-way arg-max)")
+    ap.add_argument("--rehearse-rccl", type=int, default=0, help="1 (with --gpus 1): run the N > 1 code path on a ONE-rank nccl (= RCCL) group - process-group "
+                    "init with device_id, barrier, query all-gather, list gather, max-reduce of the time, the `rccl` record - the most of the multi-GPU "
+                    "path one GPU can execute (tests); the line still says n_gpus 1")
     ap.add_argument("--launch-check", action="store_true", help="rehearse the launch path only: every rank joins the process group (gloo: no GPU "
                     "needed), all-reduces its rank and rank 0 prints one JSON line; nothing is benchmarked (tests/test_cpu_host.py)")
     return ap.parse_args(argv)
@@ -298,12 +301,19 @@ def main():
         except Exception as e:                           # noqa: BLE001 - the bench must still produce its line
             launch_mode = f"eager ctypes launches (graph capture failed: {type(e).__name__}: {e})"
 
+    rehearse = bool(args.rehearse_rccl) and world == 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+    elif rehearse:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    multi = world > 1 or rehearse                        # the collective code path runs
 
     def step():
         if h2d is not None:
@@ -312,10 +322,10 @@ def main():
         else:
             b = batch
         masks, emb, feat = graphed(**b) if graphed is not None else model(**b, multimask_output=mm)
-        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B, timing=timing)    # results on rank 0 (merged once)
+        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B, timing=timing, always_collective=rehearse)    # results on rank 0 (merged once)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -324,7 +334,7 @@ def main():
         step()
     barrier()
     prof = []
-    timing = [] if world > 1 else None                   # per-step marks around the two collectives and the shard search
+    timing = [] if multi else None                       # per-step marks around the two collectives and the shard search
     clock = utils.ClockSampler(dev).start()
     if graphed is None:
         ops.GEMM_PROFILE = prof                          # HIP events around every cor_gemm, on the launch stream
@@ -347,8 +357,8 @@ def main():
             model(**batch, multimask_output=mm)
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = None
-    if world > 1:
-        tmax = torch.tensor([dt], device="cpu" if args.backend == "gloo" else dev, dtype=torch.float64)
+    if multi:
+        tmax = torch.tensor([dt], device="cpu" if (args.backend == "gloo" and world > 1) else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -389,7 +399,7 @@ def main():
         res["config"]["multimask_output"] = mm
         res["roofline"]["events"] = events_from
         res["clock"] = clk
-        if world > 1:
+        if multi:
             res["rccl"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), **coll,
                                note="rank 0's means over the timed steps; device events on the launch stream under nccl (= RCCL), host clocks under the "
                                     "gloo rehearsal (whose collectives work on host copies); collective_ms = query all-gather + packed-list gather")
@@ -409,7 +419,7 @@ def main():
                 res["cpu_baseline"] = None
                 res["recall"] = dict(error=f"{type(e).__name__}: {e}")
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

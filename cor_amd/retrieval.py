@@ -112,7 +112,7 @@ def resolve_timing(timing: list) -> dict:
 
 
 def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int, group=None, max_local: int | None = None,
-                       dst: int | None = 0, timing: list | None = None):
+                       dst: int | None = 0, timing: list | None = None, always_collective: bool = False):
     """All ranks call this with their own queries [B_local, C] and their gallery shard.
 
     Two collectives in all, as BASELINE.json's north_star describes it:
@@ -130,10 +130,12 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
     Under the gloo REHEARSAL backend the collectives work on host copies, so every rank synchronises twice (queries, lists).
     `max_local` must be given (and equal on all ranks) whenever per-rank query counts can differ: the all-gather is fixed-size.
     timing: a list that receives one _Marks per call (resolve_timing() turns them into milliseconds after a synchronisation).
+    always_collective: take the collective path even in a group of ONE rank (tests: the only way to put this code on RCCL with a
+    single GPU - a one-rank nccl group still moves the device tensors through all_gather_into_tensor / gather).
     Returns (scores f32[B_total,k], idx i64[B_total,k]) CPU tensors, queries ordered by rank, on rank `dst` (every rank
     for dst=None); (None, None) on the other ranks."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always_collective):
         s, i = shard.search(local_queries, k)
         return s.cpu(), i.cpu()
     world, rank = dist.get_world_size(group), dist.get_rank(group)

@@ -1725,6 +1725,39 @@ def test_graph_captured_forward_equals_eager(mode):
         g(**b0)
 
 
+def test_distributed_search_on_a_one_rank_rccl_group():
+    """The multi-rank retrieval path (query all-gather, shard search over all slots, packed-list gather, host merge) on the REAL backend:
+    a one-rank `nccl` (= RCCL) process group on this box's GPU with always_collective=True. One rank moves nothing over xGMI, but
+    all_gather_into_tensor / gather run through RCCL on the device tensors this code builds (layouts, dtypes, the device-event timing
+    marks of bench.py's `rccl` record) - which no CPU gloo test can show. dst=0 and dst=None, ragged max_local."""
+    import socket
+    import torch.distributed as dist
+    from cor_amd import retrieval
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    dev = torch.device(DEV)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(11)
+        Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((5, 256), dtype=np.float32)), dim=-1).to(dev)
+        G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((12500, 256), dtype=np.float32)), dim=-1).to(BF16).to(dev)
+        shard = retrieval.GalleryShard(G, offset=100)
+        s0, i0 = shard.search(Q, 10)
+        timing = []
+        s1, i1 = retrieval.distributed_search(Q, shard, 10, max_local=8, timing=timing, always_collective=True)          # dst = 0: gather
+        s2, i2 = retrieval.distributed_search(Q, shard, 10, max_local=8, dst=None, always_collective=True)                # all-gather of the lists
+        torch.cuda.synchronize()
+        for s_, i_ in ((s1, i1), (s2, i2)):
+            assert torch.equal(i_, i0.cpu()) and torch.equal(s_.view(torch.int32), s0.cpu().view(torch.int32))
+        t = retrieval.resolve_timing(timing)
+        assert t["calls"] == 1 and t["collective_ms"] > 0 and t["search_ms"] > 0 and dist.get_backend() == "nccl"
+        _note(name="distributed_search_one_rank_rccl", **t)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bench_contract_smoke(tmp_path):
     """bench.py end to end at a reduced batch (the driver runs the default line at round end): ONE JSON line with the contract's keys,
     `roofline` and `cpu_baseline` objects, recall over all queries with the planted positives found by both pipelines."""
@@ -1747,6 +1780,19 @@ def test_bench_contract_smoke(tmp_path):
     assert rec["fp32_mode_topk_entries"] == 30 and rec["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0, rec
     assert d["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0 and d["cpu_oracle_recall_at_1"] == 1.0
     assert "clock" in d and d["config"]["multimask_output"] is True
+
+
+def test_bench_multi_rank_code_path_on_a_one_rank_rccl_group(tmp_path):
+    """bench.py --rehearse-rccl 1: the N > 1 branch of the bench (nccl process group with device_id, barrier, all-gather / gather inside the
+    step, max-reduce of the time on a device tensor, `rccl` record from device events) executed on RCCL with one rank."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-rccl", "1", "--batch", "2", "--gallery", "12500", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    rc = d["rccl"]
+    assert d["n_gpus"] == 1 and rc["backend"] == "nccl" and rc["world_size"] == 1 and rc["calls"] == 2 and rc["collective_ms"] > 0 and rc["search_ms"] > 0
 
 
 def test_bench_gpus2_gloo_rehearsal_launches_two_ranks_by_itself(tmp_path):
