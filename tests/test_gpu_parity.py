@@ -1021,6 +1021,29 @@ def test_similarity_small_shard_path_equals_the_global_threshold_path(Bq, Ng, k,
     _note(name=f"topk_small_path_{Bq}x{Ng}_k{k}_{gdt}", index_mismatches=0, score_bit_mismatches=0, entries=int(ri.numel()))
 
 
+def test_similarity_small_shard_path_random_shapes():
+    """Thirty seeded random (Bq, Ng, k, dtype) draws inside the small-shard path's domain (1..600 queries, 1..16 000 rows, k <= 16), ragged
+    in every dimension: scores and indices bitwise equal to the CPU chain oracle, no fallback taken, duplicates at random places."""
+    ops, _ = _ops()
+    from cor_amd import _native as nat
+    rng = np.random.default_rng(2024)
+    for case in range(30):
+        Bq = int(rng.integers(1, 601)); Ng = int(rng.integers(1, 16001)); k = int(rng.integers(1, 17))
+        gdt = BF16 if rng.integers(0, 2) else torch.float16
+        Q = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Bq, 256), dtype=np.float32)), dim=-1)
+        G = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((Ng, 256), dtype=np.float32)), dim=-1).to(gdt)
+        if Ng > 3:
+            a, b = (int(v) for v in rng.integers(0, Ng, 2)); G[a] = G[b]
+        s, i = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, g_offset=3)
+        _, raw = ops.similarity_topk(Q.to(DEV), G.to(DEV), k, g_offset=3, flags=nat.TOPK_NO_FALLBACK)
+        rs, ri = oret.similarity_topk_chain(Q.to(gdt).float(), G.float(), k)
+        kk = min(k, Ng)
+        assert int((raw == -2).sum()) == 0, (case, Bq, Ng, k)
+        assert torch.equal(i[:, :kk].cpu() - 3, ri) and torch.equal(s[:, :kk].cpu().view(torch.int32), rs.view(torch.int32)), (case, Bq, Ng, k, gdt)
+        if k > Ng:
+            assert (i[:, Ng:] == -1).all()
+
+
 @pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 125000, 10, torch.float16), (300, 70001, 5, BF16), (64, 40000, 10, BF16), (512, 3000, 16, BF16)])
 def test_similarity_wave_selection_equals_the_block_selection_kernel(Bq, Ng, k, gdt):
     """Global-threshold pipeline: the round-4 form (SAMPLE pass converts the queries itself, ballot-counting sim_tau, one-wave-per-query
