@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
   };
 
   for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
+  // (s_setprio 1 for the younger half - waves 4-7 - before the loop, the guide's static-priority item: 512 x 1M 268-272 -> 324-328 us, not kept)
   int g_pending = -1;                                  // late waves: tile whose epilogue is still owed
   for (int t = t0; t < t1; ++t) {
     // super-tile t has landed once at most 4 * (super-tiles issued after t) of this wave's DMA are still outstanding (VMEM
