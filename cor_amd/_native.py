@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcor_amd.so")
+LIB_PATH = os.environ.get("COR_AMD_LIB") or os.path.join(_HERE, "csrc", "libcor_amd.so")   # COR_AMD_LIB: another build of the SAME ABI (same-box A/B runs of tools/)
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_RELU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4

@@ -451,7 +451,9 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
   };
 
   for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
-  // (s_setprio 1 for the younger half - waves 4-7 - before the loop, the guide's static-priority item: 512 x 1M 268-272 -> 324-328 us, not kept)
+  // (s_setprio 1 for the younger half - waves 4-7 - before the loop, the guide's static-priority item, and a sample stride of 32 instead of 16
+  // at 1M rows: no difference in a same-box A/B - 320-333 us for all three builds on a box where this clock-bound kernel runs 20 % slower than
+  // on the round's other boxes, 268-272; a first cross-box comparison had read the box as the change. Not kept.)
   int g_pending = -1;                                  // late waves: tile whose epilogue is still owed
   for (int t = t0; t < t1; ++t) {
     // super-tile t has landed once at most 4 * (super-tiles issued after t) of this wave's DMA are still outstanding (VMEM
