@@ -1413,8 +1413,9 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   // every wave converting its own 64 fp32 rows, the blocks of slice 0 publishing the image - was built and measured in round 4: the
   // SAMPLE pass grew from 8-10 to 21.6 us at 125k rows and from 22.7 to 37 us at 1M, against the 5.6-us launch it replaced: reverted. A
   // second form - COALESCED 1-KiB row loads, transposed into fragments through the wave's 16 KiB of the idle gallery ring - costs the
-  // SAMPLE pass +4.5 us (every block still pulls 512 KiB of fp32 rows through its CU's L2 port against 256 KiB of the image) and the whole
-  // call +3..+8 us at 125k / 1M rows: reverted too. The 5-us launch is the cheapest way to convert 512 queries once.)
+  // SAMPLE pass +4.5 us (every block still pulls 512 KiB of fp32 rows through its CU's L2 port against 256 KiB of the image) and saves
+  // the 5-us launch + its boundary: NO difference in a same-box A/B (three alternating rounds: 512 x 125k 84.6-88.4 vs 86.7-87.9 us,
+  // 512 x 1M 319-321 vs 316-327, 256 x 100k 56.3-56.9 vs 55.6-56.1). The launch stays: it is the simpler code.)
   hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
   COR_CHECK_LAUNCH();
   ScanArgs a{};
