@@ -289,11 +289,14 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 // v3 (16-bit galleries, C = 256, every shard size): threshold-and-append with EXACT re-scoring.
 // Per-lane sorted lists cost one divergent insertion bubble (~500 wave cycles) per accepted score, and a stream of n scores
-// accepts ~k ln(n/k) of them per lane: measured 9x the MFMA time. Instead, four launches:
+// accepts ~k ln(n/k) of them per lane: measured 9x the MFMA time. Instead, four launches (sim_prep + these three):
 //   A. sim_scan<SAMPLE>: MFMA scores of a strided SAMPLE of 32-row tiles; every (gallery slice, lane half) group keeps only
-//      its MAXIMUM per query. The groups are disjoint row sets, so the k-th largest group maximum is a LOWER bound of the
-//      query's k-th best score over the whole shard (no dense score matrix, no selection pass).
-//   B. sim_tau: tau_q = that k-th largest group maximum minus delta_q (one wave per query).
+//      its MAXIMUM per query and folds it (atomic max on order-preserving keys) into one of 32 SUPER-GROUPS per query. The
+//      super-groups are disjoint row sets, so the k-th largest of their maxima is a LOWER bound of the query's k-th best score over
+//      the whole shard (no dense score matrix, no selection pass).
+//   B. tau_q = that k-th largest maximum minus delta_q: ranked in the PROLOGUE of pass C (thread <-> query, a 32-element bitonic
+//      network in registers). Rounds 2-3 ranked all 512 group maxima in a launch of their own (sim_tau, 5-7 us, launch-bound); the
+//      32 unions admit ~15 % more candidates and cost the prologue ~3 us: one launch fewer, 0-2 % faster in a same-box A/B.
 //   C. sim_scan<APPEND>: MFMA scores of the WHOLE shard; a lane compares its tile maximum with tau_q and appends the rare
 //      scores >= tau_q to the private list of its (query, gallery slice, lane half) stream (register counter, no atomics).
 //   D. sim_final: per query, the candidates are compacted into LDS, the k-th best MFMA score T is found by a 4-pass radix
@@ -321,9 +324,11 @@ struct ScanArgs {
   int ntiles;                      // 64-row super-tiles this launch walks (SAMPLE: sample super-tiles; APPEND: all of them)
   int tile_stride;                 // super-tiles between consecutive walked super-tiles (SAMPLE: >= 1; APPEND: 1)
   const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep)
-  float* pmax; int ngroups;        // SAMPLE: pmax[q * ngroups + split * 2 + h]
+  unsigned* sg; int Bqp;           // 32 SUPER-GROUP maxima per query as order-preserving keys, sg[g * Bqp + q] (zeroed by sim_prep; 0 = empty):
+                                   // SAMPLE: atomic max of the group (slice, lane half) maximum into super-group (split * 2 + h) & 31; APPEND: read
+  const float* dq; int k;          // APPEND: delta_q (sim_prep) and k: tau_q = k-th largest super-group maximum - delta_q, computed in the prologue
   float tau_add;                   // 0; timing-only ablation (COR_TOPK_DEBUG_NOCAND): +1e30 = no candidate ever passes
-  const float* tau; int* cnt; float* rec_s; int* rec_g; int cap;     // APPEND: record i of stream (q, slice, half): 16 scores + first row
+  float* tau; int* cnt; float* rec_s; int* rec_g; int cap;           // APPEND: tau_q (written by the blocks of slice 0 for the selection kernel); record i of stream (q, slice, half): 16 scores + first row
 };
 
 // One block = 8 waves = 256 * QB queries (wave w owns queries q0 + 32 * QB * w ..): with QB = 2 all 512 queries of an
@@ -337,6 +342,12 @@ struct ScanArgs {
 // accumulators before the matrix pipe had written them (sporadic missed candidates). The file is built with -fno-honor-nans
 // (Makefile) so that fmaxf needs no canonicalising v_max x,x,x per operand and folds to v_max3_f32 by itself.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// order-preserving float <-> unsigned keys (0 is below every float's key: "empty")
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f_floor(unsigned key) {      // the smallest float whose order-preserving key is >= key's prefix
+  const unsigned u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+  return __uint_as_float(u);
+}
 
 template <typename TG, int QB, bool SAMPLE>
 __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, const ScanArgs a) {
@@ -353,6 +364,40 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
   // double buffering is needed.
   const bool late = wave >= 4;
 
+  // APPEND: tau_q in the prologue (round 4: no sim_tau launch). Thread <-> query of this block: its 32 super-group maxima, a 32-element
+  // bitonic network in registers (the K-fragments are not loaded yet), tau_q = k-th largest - delta_q (fewer than k non-empty super-groups:
+  // -inf, every row is a candidate). Any lower bound of the k-th best score is valid, so 32 unions of the (slice, lane half) groups serve
+  // as well as the 512 groups the launch ranked (~15 % more candidates).
+  __shared__ float tau_s[256 * QB];
+  if (!SAMPLE) {
+    const int ql = tid;                                // 256 * QB queries per block, 512 threads
+    if (ql < 256 * QB) {
+      const int qg_ = min(qg * (256 * QB) + ql, a.Bq - 1);
+      float v[32];
+#pragma unroll
+      for (int g = 0; g < 32; ++g) { const unsigned key = a.sg[(long)g * a.Bqp + qg_]; v[g] = key == 0u ? -INFINITY : key2f_floor(key); }
+#pragma unroll
+      for (int kk = 2; kk <= 32; kk <<= 1)
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1)
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+            const int l = i ^ j;
+            if (l > i) {
+              const float x = v[i], y = v[l];
+              if ((i & kk) == 0) { v[i] = fmaxf(x, y); v[l] = fminf(x, y); }
+              else               { v[i] = fminf(x, y); v[l] = fmaxf(x, y); }
+            }
+          }
+      float kth = v[0];
+#pragma unroll
+      for (int c = 1; c < 32; ++c) kth = (c == a.k - 1) ? v[c] : kth;
+      const float t = kth - a.dq[qg_];                 // -inf stays -inf
+      tau_s[ql] = t;
+      if (split == 0 && qg * (256 * QB) + ql < a.Bq) a.tau[qg * (256 * QB) + ql] = t;      // for the selection kernel
+    }
+    __syncthreads();
+  }
   uint4 qf[QB][16];
   float tau[QB], gmax[QB];
   int ncand[QB];
@@ -365,7 +410,7 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
 #pragma unroll
     for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
     const int q = min(q0 + qb * 32 + r, a.Bq - 1);
-    tau[qb] = SAMPLE ? 0.f : a.tau[q] + a.tau_add;
+    tau[qb] = SAMPLE ? 0.f : tau_s[wave * (32 * QB) + qb * 32 + r] + a.tau_add;
     gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
@@ -481,7 +526,7 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     for (int qb = 0; qb < QB; ++qb) {
       const int q = q0 + qb * 32 + r;
       if (q < a.Bq) {
-        if (SAMPLE) a.pmax[(long)q * a.ngroups + split * 2 + h] = gmax[qb];
+        if (SAMPLE) atomicMax(a.sg + (long)((split * 2 + h) & 31) * a.Bqp + q, f2key(gmax[qb]));     // (a group without a tile: key(-inf) > 0 = empty)
         else a.cnt[(long)q * nstreams + split * 2 + h] = ncand[qb];
       }
     }
@@ -492,60 +537,43 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
 // [16c + 8(lane>>5) .. +8]; rows beyond Bq repeat the last query (their results are never written). Also clears the per-call
 // overflow flags. One block of 256 threads per 32 queries.
 template <typename TG>
-__global__ void __launch_bounds__(256) sim_prep(const float* __restrict__ Q, int Bq, uint4* img, int* flags, int* ovf_q) {
+__global__ void __launch_bounds__(256) sim_prep(const float* __restrict__ Q, int Bq, uint4* img, int* flags, int* ovf_q, unsigned* sg, int Bqp,
+                                                float* dq) {
+  __shared__ float part[32][33];                       // |q|^2 partials of the block's 32 queries: [query][K-step * 2 + lane half]
   const int qblk = blockIdx.x, tid = threadIdx.x;
   if (qblk == 0 && tid == 0) flags[0] = 0;
   if (tid < 32 && qblk * 32 + tid < Bq) ovf_q[qblk * 32 + tid] = 0;
 #pragma unroll
+  for (int i = 0; i < 4; ++i) sg[(long)(tid >> 5 | (i << 3)) * Bqp + qblk * 32 + (tid & 31)] = 0u;     // the 32 super-group maxima of these queries: empty
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int item = tid + 256 * i, c = item >> 6, lane = item & 63, r = lane & 31, h = lane >> 5;
     const float* qrow = Q + (long)min(qblk * 32 + r, Bq - 1) * 256;
-    img[((long)qblk * 16 + c) * 64 + lane] = q_frag16<TG>(qrow, c, h);
+    const uint4 f = q_frag16<TG>(qrow, c, h);
+    img[((long)qblk * 16 + c) * 64 + lane] = f;
+    float n2 = 0.f;                                    // of the values as the MFMA sees them
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo, hi;
+      if (__is_same(TG, bf16_t)) { lo = __uint_as_float(w[j] << 16); hi = __uint_as_float(w[j] & 0xffff0000u); }
+      else { typedef _Float16 h2 __attribute__((ext_vector_type(2))); const h2 t2 = __builtin_bit_cast(h2, w[j]); lo = (float)t2[0]; hi = (float)t2[1]; }
+      n2 = fmaf(lo, lo, n2); n2 = fmaf(hi, hi, n2);
+    }
+    part[r][c * 2 + h] = n2;
+  }
+  __syncthreads();
+  if (tid < 32 && qblk * 32 + tid < Bq) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) n2 += part[tid][j];   // fixed order: delta_q is reproducible
+    dq[qblk * 32 + tid] = SIM_DELTA * fmaxf(1.f, sqrtf(n2));
   }
 }
 
-__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-__device__ __forceinline__ float key2f_floor(unsigned key) {      // the smallest float whose order-preserving key is >= key's prefix
-  const unsigned u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
-  return __uint_as_float(u);
-}
 template <typename TG> __device__ __forceinline__ float round_to(float x);
 template <> __device__ __forceinline__ float round_to<bf16_t>(float x) { return bf2f(f2bf(x)); }
 template <> __device__ __forceinline__ float round_to<_Float16>(float x) { return (float)(_Float16)x; }
-
-// tau_q = (k-th largest of the query's group maxima) - delta_q ; one wave per query, ngroups <= 512 (8 values per lane).
-// ngroups < k (or no sample at all: ngroups == 0) gives -inf: every row is then a candidate.
-template <typename TG>
-__global__ void __launch_bounds__(256) sim_tau(const float* __restrict__ Q, const float* __restrict__ pmax, int ngroups, int Bq, int k,
-                                               float* tau) {
-  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= Bq) return;
-  float nrm = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const float v = round_to<TG>(Q[(long)q * 256 + lane * 4 + i]); nrm = fmaf(v, v, nrm); }
-  nrm = sqrtf(wave_sum(nrm));
-  // k-th largest of the group maxima, floored to 20 key bits (any lower bound of it is valid): counting binary search - every
-  // step is 8 compares + 8 ballots + scalar bit counts (the round-2 form ran k rounds of a 6-step ds_bpermute maximum: ~3.5 us of
-  // dependent LDS round trips per query)
-  unsigned key[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) key[i] = f2key((lane + 64 * i < ngroups) ? pmax[(long)q * ngroups + lane + 64 * i] : -INFINITY) >> 12;
-  float kth = -INFINITY;
-  if (ngroups >= k) {
-    unsigned lo = 0x007FFu, hi = 0x100000u;             // 0x007FF = key prefix of -inf
-#pragma unroll 1
-    for (int it = 0; it < 20; ++it) {
-      const unsigned mid = (lo + hi) >> 1;
-      int c = 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] >= mid));
-      if (c >= k) lo = mid; else hi = mid;
-    }
-    kth = lo == 0x007FFu ? -INFINITY : key2f_floor(lo << 12);
-  }
-  if (lane == 0) tau[q] = kth - SIM_DELTA * fmaxf(1.f, nrm);      // -inf stays -inf
-}
-
 
 // chain score of gallery row `idx` against the query in LDS (oracle/c/sim_chain.c order: chunk c of 8: k = 8c+i then 8c+4+i)
 template <typename TG>
@@ -1323,7 +1351,7 @@ struct V3Plan {
   int qb, nqg;                       // query blocks per wave (1 | 2), query groups of 256 * qb
   int tiles, nsplit, tiles_per_split, nstreams, cap;                 // APPEND pass
   int s_stride, s_tiles, s_nsplit, s_tiles_per_split, ngroups;       // SAMPLE pass (ngroups == 0: no sample, tau = -inf)
-  size_t off_img, off_pmax, off_tau, off_flags, off_ovf, off_cnt, off_recs, off_recg, off_lists, bytes;
+  size_t off_img, off_sg, off_dq, off_tau, off_flags, off_ovf, off_cnt, off_recs, off_recg, off_lists, bytes;
 };
 inline V3Plan make_v3(int Bq, int Ng, int k) {
   V3Plan p{};
@@ -1331,7 +1359,7 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
   p.nqg = cdiv(Bq, 256 * p.qb);
   p.tiles = cdiv(Ng, 64);                              // 64-row super-tiles
   int want = device_cus() / p.nqg;                     // one resident block per CU
-  if (want > 256) want = 256;                          // nstreams <= 512 (sim_tau holds 8 group maxima per lane)
+  if (want > 256) want = 256;                          // nstreams <= 512
   if (want > p.tiles) want = p.tiles;
   if (want < 1) want = 1;
   p.tiles_per_split = cdiv(p.tiles, want);
@@ -1361,7 +1389,8 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
   p.off_img = take((size_t)p.nqg * 8 * p.qb * 16 * 64 * 16);        // whole query blocks of every group (rows past Bq: copies)
-  p.off_pmax = take((size_t)Bq * (p.ngroups > 0 ? p.ngroups : 1) * 4);
+  p.off_sg = take((size_t)32 * p.nqg * 256 * p.qb * 4);               // 32 super-group maxima per query slot (whole query blocks)
+  p.off_dq = take((size_t)Bq * 4);
   p.off_tau = take((size_t)Bq * 4);
   p.off_flags = take(16);
   p.off_ovf = take((size_t)Bq * 4);
@@ -1405,7 +1434,8 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   cor_max_dyn_lds((const void*)sim_scan<TG, QB, false>, (int)lds, once_a);
   constexpr size_t fs_lds = (size_t)FS_MAX * 8 + SL_MAX * 8 + 256 * 4 + 256 * 4;
   cor_max_dyn_lds((const void*)sim_final<TG>, (int)fs_lds, once_f);
-  float* pmax = (float*)(w + p.off_pmax); float* tau = (float*)(w + p.off_tau);
+  unsigned* sg = (unsigned*)(w + p.off_sg); float* dq = (float*)(w + p.off_dq); float* tau = (float*)(w + p.off_tau);
+  const int Bqp = p.nqg * 256 * QB;
   int* dflags = (int*)(w + p.off_flags); int* ovf_q = (int*)(w + p.off_ovf); int* cnt = (int*)(w + p.off_cnt);
   float* rec_s = (float*)(w + p.off_recs); int* rec_g = (int*)(w + p.off_recg);
   uint4* qimg = (uint4*)(w + p.off_img);
@@ -1416,21 +1446,19 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   // SAMPLE pass +4.5 us (every block still pulls 512 KiB of fp32 rows through its CU's L2 port against 256 KiB of the image) and saves
   // the 5-us launch + its boundary: NO difference in a same-box A/B (three alternating rounds: 512 x 125k 84.6-88.4 vs 86.7-87.9 us,
   // 512 x 1M 319-321 vs 316-327, 256 x 100k 56.3-56.9 vs 55.6-56.1). The launch stays: it is the simpler code.)
-  hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q);
+  hipLaunchKernelGGL((sim_prep<TG>), dim3(p.nqg * 8 * QB), dim3(256), 0, s, Q, Bq, qimg, dflags, ovf_q, sg, Bqp, dq);
   COR_CHECK_LAUNCH();
   ScanArgs a{};
-  a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg; a.qimg = qimg;
+  a.Bq = Bq; a.Ng = Ng; a.nqg = p.nqg; a.qimg = qimg; a.sg = sg; a.Bqp = Bqp;
   if (p.ngroups > 0) {                                  // A. group maxima of the strided sample
     a.nsplit = p.s_nsplit; a.tiles_per_split = p.s_tiles_per_split; a.ntiles = p.s_tiles; a.tile_stride = p.s_stride;
-    a.pmax = pmax; a.ngroups = p.ngroups;
     hipLaunchKernelGGL((sim_scan<TG, QB, true>), dim3(p.nqg * p.s_nsplit), dim3(512), lds, s, G, a);
     COR_CHECK_LAUNCH();
   }
-  // B. tau (ngroups == 0: -inf)
-  hipLaunchKernelGGL((sim_tau<TG>), dim3(cdiv(Bq, 4)), dim3(256), 0, s, Q, pmax, p.ngroups, Bq, k, tau);
-  COR_CHECK_LAUNCH();
+  // B. (round 4: no sim_tau launch - the APPEND pass ranks the 32 super-group maxima in its prologue; no sample pass: all empty, tau = -inf)
   // C. full scan
   a.nsplit = p.nsplit; a.tiles_per_split = p.tiles_per_split; a.ntiles = p.tiles; a.tile_stride = 1;
+  a.dq = dq; a.k = k;
   a.tau = tau; a.cnt = cnt; a.rec_s = rec_s; a.rec_g = rec_g; a.cap = p.cap; a.tau_add = (flags & 4) ? 1e30f : 0.f;
   hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, G, a);
   COR_CHECK_LAUNCH();

@@ -234,8 +234,8 @@ int cor_resample_cols_u8(const unsigned char* in, float* out_f32, unsigned char*
  * blocks, k <= 16: the 8-GPU shard shapes, 256..512 queries x 12.5k rows) in TWO launches with block-local thresholds (sim_block_scan:
  * every block bounds its queries' k-th best score from the maxima of 32 disjoint row classes of its own slice and appends what passes;
  * sim_final_wave: one wave per query selects, re-scores, ranks); everything else by threshold-and-append with a GLOBAL threshold (a strided
- * sample pass bounds each query's k-th best score, the full MFMA pass appends the rare score records above the bound, the final pass
- * re-scores the short list). If a query's candidate list overflows (pathological score distributions, e.g. hundreds of identical rows)
+ * sample pass bounds each query's k-th best score by 32 super-group maxima, the full MFMA pass ranks them in its prologue and appends the
+ * rare score records above the bound, the final pass re-scores the short list: four launches). If a query's candidate list overflows (pathological score distributions, e.g. hundreds of identical rows)
  * it is ranked by an exact brute-force chain pass ON THE DEVICE (no host round trip). `flags` (per call, no process-global state):
  * 0 = default; COR_TOPK_FORCE_LISTS = per-lane sorted-list kernels only; COR_TOPK_NO_FALLBACK = report an overflow as index -2 in every
  * slot of the query instead of falling back (tests); COR_TOPK_FORCE_GLOBAL_THRESHOLD / COR_TOPK_WAVE_FINAL = A/B partners (tests). */
