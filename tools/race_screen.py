@@ -48,6 +48,16 @@ for it in range(rounds):
     nd = int((i1 != i3).sum())
     if not (torch.equal(i1, i2) and torch.equal(s1, s2)) or nd > 8 or float((s1 - s3).abs().max()) > 1e-5:
         bad += 1; print("SIM MISMATCH", it, bool(torch.equal(i1, i2)), nd, float((s1 - s3).abs().max()), flush=True)
+    # round 4: sim_block_scan (per-wave private LDS-DMA buffers with counted waits, exec-masked asm appends behind one LDS atomic) and
+    # sim_final_wave (LDS-DMA row staging): the small-shard path on fresh data of ragged size, run twice, bit-equal to the
+    # global-threshold pipeline (whose APPEND pass now ranks the super-group maxima the SAMPLE pass folded in with atomics)
+    for (bq, ng) in ((512, 12500 + 13 * it), (256, 12500 - 7 * it), (40, 3000 + it)):
+        Qs = torch.nn.functional.normalize(torch.randn((bq, 256), device=dev), dim=-1)
+        Gs = torch.nn.functional.normalize(torch.randn((ng, 256), device=dev), dim=-1).to(T)
+        a1, b1 = ops.similarity_topk(Qs, Gs, 10); a2, b2 = ops.similarity_topk(Qs, Gs, 10)
+        a3, b3 = ops.similarity_topk(Qs, Gs, 10, flags=_native.TOPK_FORCE_GLOBAL_THRESHOLD)
+        if not (torch.equal(b1, b2) and torch.equal(a1, a2) and torch.equal(b1, b3) and torch.equal(a1, a3)):
+            bad += 1; print("SIM SMALL-PATH MISMATCH", it, bq, ng, int((b1 != b2).sum()), int((b1 != b3).sum()), flush=True)
     if it % 5 == 4: print("round", it + 1, "ok so far" if not bad else f"{bad} mismatches", flush=True)
 print("FAILED" if bad else "RACE SCREEN CLEAN", rounds, "rounds")
 sys.exit(1 if bad else 0)
