@@ -429,9 +429,7 @@ _SIDE = {}
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _SIDE:
-        import os
-        prio = os.environ.get("COR_SIDE_STREAM_PRIORITY")       # experiments only (tools): HIP stream priority of the support-branch stream
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=int(prio)) if prio else torch.cuda.Stream(device=device)
+        _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
 
 
