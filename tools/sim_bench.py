@@ -2,8 +2,8 @@
 """GPU micro-benchmark of cor_similarity_topk (gallery similarity + top-k) at the BASELINE shard shapes.
     python tools/sim_bench.py            # all shapes, one JSON line each (roofline of the similarity GEMM included)
     python tools/sim_bench.py 1m [reps]  # only 512 x 1M bf16, `reps` calls (for rocprofv3 --kernel-trace / --pmc passes)
-Time = all launches of one call (sample scan + tau + full scan + final selection + gated fallback), HIP events on the
-launch stream. Roofline: MFMA-bound when B_tot >= ~400 (2*Bq*256*Ng flop against 2.5 PF dense bf16), HBM-bound below
+Time = all launches of one call (small shards: block scan + wave selection; otherwise prep + sample scan + full scan + selection),
+HIP events on the launch stream. Roofline: MFMA-bound when B_tot >= ~400 (2*Bq*256*Ng flop against 2.5 PF dense bf16), HBM-bound below
 (Ng*256*2 B against 8 TB/s): the line reports both fractions."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,4 +47,4 @@ for Bq, Ng, k, dt in SHAPES:
                           tflops=fl / tb / 1e12,
                           roofline=dict(bound="mfma" if Bq >= 400 else "hbm", achieved=fl / tb / 1e12, peak=peak, unit="TFLOP/s", frac=fl / tb / 1e12 / peak,
                                         gallery_GBps=gbytes / tb / 1e9, hbm_frac=gbytes / tb / 8e12, algorithmic_bytes=gbytes + Bq * 1024,
-                                        note="whole call (prep + sample scan + tau + full scan + final selection), calls enqueued back to back"))), flush=True)
+                                        note="whole call (every launch of cor_similarity_topk), calls enqueued back to back"))), flush=True)
