@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL, default) | gloo (rehearsal: several ranks on ONE GPU)")
     ap.add_argument("--multimask", type=int, default=1, help="multimask_output of the forward (1: three masks + IoU arg-max select, as in rounds 1-3; "
                     "0: the reference's shipped config/vaild_config/vaild_config.yaml:13 - skips cor_iou_select's 3-way arg-max)")
+    ap.add_argument("--defer", type=int, default=1, help="1 (default): a step's top-k lists go to pinned host memory behind an event and are awaited / merged on "
+                    "the host AFTER the next step has been enqueued (the GPU does not idle through the host's turn; every step's result is on the host "
+                    "before the timed region ends); 0: await each step's result before enqueuing the next (rounds 1-3)")
     ap.add_argument("--rehearse-rccl", type=int, default=0, help="1 (with --gpus 1): run the N > 1 code path on a ONE-rank nccl (= RCCL) group - process-group "
                     "init with device_id, barrier, query all-gather, list gather, max-reduce of the time, the `rccl` record - the most of the multi-GPU "
                     "path one GPU can execute (tests); the line still says n_gpus 1")
@@ -322,7 +325,8 @@ def main():
         else:
             b = batch
         masks, emb, feat = graphed(**b) if graphed is not None else model(**b, multimask_output=mm)
-        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B, timing=timing, always_collective=rehearse)    # results on rank 0 (merged once)
+        # defer: the lists' device-to-host copy is enqueued behind an event; the host merge of step i runs after step i + 1 is enqueued
+        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B, timing=timing, always_collective=rehearse, defer=True)   # (awaited at once under --defer 0)
 
     def barrier():
         if multi:
@@ -331,7 +335,7 @@ def main():
 
     timing = None
     for _ in range(args.warmup):
-        step()
+        step().result()
     barrier()
     prof = []
     timing = [] if multi else None                       # per-step marks around the two collectives and the shard search
@@ -339,8 +343,15 @@ def main():
     if graphed is None:
         ops.GEMM_PROFILE = prof                          # HIP events around every cor_gemm, on the launch stream
     t0 = time.perf_counter()
+    pend = None
     for _ in range(args.steps):
-        out = step()
+        cur = step()                                     # forward + search of this step are enqueued ...
+        if not args.defer:
+            cur.result()
+        if pend is not None:
+            out = pend.result()                          # ... before the previous step's lists are awaited and merged on the host
+        pend = cur
+    out = pend.result()                                  # every step's top-k is materialised on the host inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     clk = clock.stop()
@@ -397,6 +408,8 @@ def main():
         }
         res["config"]["launch"] = launch_mode
         res["config"]["multimask_output"] = mm
+        res["config"]["results"] = ("every step's top-k lists reach the host inside the timed region; step i's lists are awaited and merged after step i + 1 "
+                                    "is enqueued (pinned copy behind an event)") if args.defer else "each step's top-k lists are awaited before the next step is enqueued"
         res["roofline"]["events"] = events_from
         res["clock"] = clk
         if multi:

@@ -111,8 +111,36 @@ def resolve_timing(timing: list) -> dict:
     return dict(calls=len(timing), allgather_ms=ag, search_ms=se, gather_ms=ga, collective_ms=ag + ga)
 
 
+class PendingSearch:
+    """A search whose lists are still on their way to the host (distributed_search(..., defer=True)): the ONE device-to-host copy
+    went to pinned memory behind an event, so the caller can enqueue the next step's forward first and call result() afterwards -
+    the GPU never waits for the host merge. result() -> (scores, idx) CPU tensors on `dst` (every rank for dst=None), (None, None)
+    elsewhere; idempotent."""
+
+    def __init__(self, finish=None, event=None, value=None):
+        self._finish, self._event, self._value = finish, event, value
+
+    def result(self):
+        if self._finish is not None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._value, self._finish, self._event = self._finish(), None, None
+        return self._value
+
+
+def _to_host_async(t: torch.Tensor):
+    """Device tensor -> pinned host tensor, non-blocking, + the event that marks the copy's completion on the current stream."""
+    if not t.is_cuda:
+        return t, None
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    return h, ev
+
+
 def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int, group=None, max_local: int | None = None,
-                       dst: int | None = 0, timing: list | None = None, always_collective: bool = False):
+                       dst: int | None = 0, timing: list | None = None, always_collective: bool = False, defer: bool = False):
     """All ranks call this with their own queries [B_local, C] and their gallery shard.
 
     Two collectives in all, as BASELINE.json's north_star describes it:
@@ -132,11 +160,16 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
     timing: a list that receives one _Marks per call (resolve_timing() turns them into milliseconds after a synchronisation).
     always_collective: take the collective path even in a group of ONE rank (tests: the only way to put this code on RCCL with a
     single GPU - a one-rank nccl group still moves the device tensors through all_gather_into_tensor / gather).
+    defer: return a PendingSearch instead of the tensors: the device-to-host copy is enqueued (pinned memory + event) and the host merge
+    happens in its result() - call it after enqueuing the next step's forward, so that the GPU does not idle through the host's turn.
     Returns (scores f32[B_total,k], idx i64[B_total,k]) CPU tensors, queries ordered by rank, on rank `dst` (every rank
     for dst=None); (None, None) on the other ranks."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always_collective):
         s, i = shard.search(local_queries, k)
+        if defer:
+            both, ev = _to_host_async(_pack_lists(s, i))         # one copy instead of two
+            return PendingSearch(lambda: _unpack_lists(both), ev)
         return s.cpu(), i.cpu()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     q = local_queries.reshape(-1, local_queries.shape[-1]).to(torch.float32).contiguous()
@@ -175,17 +208,25 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
         if marks:
             marks.mark(); timing.append(marks)
         if rank != dst:
-            return None, None
+            return PendingSearch(value=(None, None)) if defer else (None, None)
         parts = torch.stack(glist, dim=0)
     # the ONE device-to-host copy: lists of all shards + the per-rank counts (as int32) in one buffer
     counts_i = allb[:, cap, 0].to(torch.int32)
-    host = torch.cat([parts.reshape(-1), counts_i.to(parts.device)]).cpu()
-    counts = host[-world:].tolist()
-    if any(c < 0 or c > cap for c in counts):
-        raise RuntimeError(f"distributed_search: inconsistent per-rank query counts {counts} for max_local={cap}")
-    ps, pi = _unpack_lists(host[:-world].view(parts.shape))      # [world(shard), world*cap(slot), k]
-    keep = torch.cat([torch.arange(r * cap, r * cap + counts[r]) for r in range(world)])
-    return merge_topk_host(list(ps[:, keep]), list(pi[:, keep]), k)
+    flat = torch.cat([parts.reshape(-1), counts_i.to(parts.device)])
+    pshape = tuple(parts.shape)
+
+    def finish(host):
+        counts = host[-world:].tolist()
+        if any(c < 0 or c > cap for c in counts):
+            raise RuntimeError(f"distributed_search: inconsistent per-rank query counts {counts} for max_local={cap}")
+        ps, pi = _unpack_lists(host[:-world].view(pshape))       # [world(shard), world*cap(slot), k]
+        keep = torch.cat([torch.arange(r * cap, r * cap + counts[r]) for r in range(world)])
+        return merge_topk_host(list(ps[:, keep]), list(pi[:, keep]), k)
+
+    if defer:
+        host, ev = _to_host_async(flat)
+        return PendingSearch(lambda: finish(host), ev)
+    return finish(flat.cpu())
 
 
 @torch.no_grad()

@@ -48,6 +48,13 @@ def _worker(rank, world, port, G, Q_all, k, split, out):
         ref = [(out["s"], out["i"])] if rank == 0 else [None]
         dist.broadcast_object_list(ref, src=0)
         assert torch.equal(ref[0][1], i2) and torch.equal(ref[0][0], s2)
+        # (2b) deferred form: the same answer out of PendingSearch.result(), (None, None) off the destination rank, idempotent
+        pend = retrieval.distributed_search(Q_all[qlo:qhi], shard, k, max_local=cap, defer=True)
+        s3, i3 = pend.result()
+        if rank == 0:
+            assert torch.equal(i3, out["i"]) and torch.equal(s3, out["s"]) and pend.result()[1] is i3
+        else:
+            assert s3 is None and i3 is None
         # (3) more local queries than max_local must raise BEFORE any collective (same on every rank here)
         with pytest.raises(ValueError):
             retrieval.distributed_search(Q_all, shard, k, max_local=1)

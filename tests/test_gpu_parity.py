@@ -1771,8 +1771,11 @@ def test_distributed_search_on_a_one_rank_rccl_group():
         timing = []
         s1, i1 = retrieval.distributed_search(Q, shard, 10, max_local=8, timing=timing, always_collective=True)          # dst = 0: gather
         s2, i2 = retrieval.distributed_search(Q, shard, 10, max_local=8, dst=None, always_collective=True)                # all-gather of the lists
+        pend = retrieval.distributed_search(Q, shard, 10, max_local=8, always_collective=True, defer=True)                # pinned copy behind an event
+        pend_local = retrieval.distributed_search(Q, shard, 10, defer=True)                                               # the one-rank shortcut, deferred
+        s3, i3 = pend.result(); s4, i4 = pend_local.result()
         torch.cuda.synchronize()
-        for s_, i_ in ((s1, i1), (s2, i2)):
+        for s_, i_ in ((s1, i1), (s2, i2), (s3, i3), (s4, i4)):
             assert torch.equal(i_, i0.cpu()) and torch.equal(s_.view(torch.int32), s0.cpu().view(torch.int32))
         t = retrieval.resolve_timing(timing)
         assert t["calls"] == 1 and t["collective_ms"] > 0 and t["search_ms"] > 0 and dist.get_backend() == "nccl"
@@ -1802,7 +1805,7 @@ def test_bench_contract_smoke(tmp_path):
     # exact-fp32 HIP pipeline end to end vs the CPU oracle end to end: top-k INDICES identical (north_star)
     assert rec["fp32_mode_topk_entries"] == 30 and rec["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0, rec
     assert d["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0 and d["cpu_oracle_recall_at_1"] == 1.0
-    assert "clock" in d and d["config"]["multimask_output"] is True
+    assert "clock" in d and d["config"]["multimask_output"] is True and "awaited and merged after step i + 1" in d["config"]["results"]
 
 
 def test_bench_multi_rank_code_path_on_a_one_rank_rccl_group(tmp_path):
