@@ -1737,6 +1737,14 @@ def test_graph_captured_forward_equals_eager(mode):
         got = g(**batch, clone=True)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+    # back to back WITHOUT host synchronisation between replays (bench.py awaits step i's results after enqueuing step i + 1): the
+    # parallel support branch of replay i + 1 must not start on replay i's buffers - every replay's cloned outputs (the clone is
+    # enqueued right behind its replay) equal the synchronised ones, for alternating inputs
+    outs = [g(**batch, clone=True) for batch in (b0, b1) * 6]
+    torch.cuda.synchronize()
+    for n, got in enumerate(outs):
+        for a, b in zip(got, (e0, e1)[n % 2]):
+            assert torch.equal(a, b), n
     host = {k: v.cpu() for k, v in b1.items()}                        # CPU tensors are copied over
     for a, b in zip(g(**host), e1):
         assert torch.equal(a, b)
