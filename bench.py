@@ -27,6 +27,7 @@ same gallery with one planted positive per query; inputs are per-sample texture 
 from __future__ import annotations
 
 import argparse
+import collections
 import json
 import os
 import sys
@@ -50,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=-1, help="1: support branch (SigLIP towers, adapter, fusion) beside the SAM encoder: a parallel branch of "
+    ap.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1, 2], help="2: as 1, with the two SigLIP towers as two chains on two streams (round 4); 1: support branch (SigLIP towers, adapter, fusion) beside the SAM encoder: a parallel branch of "
                     "the captured graph / a second HIP stream in eager mode (+3-4 %% end to end). -1 (default): on under --graph 1, off in eager mode, "
                     "where concurrent kernels would inflate the per-launch GEMM events")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): the timed steps replay the forward as ONE captured hipGraph "
@@ -65,6 +66,9 @@ def parse(argv=None):
     ap.add_argument("--defer", type=int, default=1, help="1 (default): a step's top-k lists go to pinned host memory behind an event and are awaited / merged on "
                     "the host AFTER the next step has been enqueued (the GPU does not idle through the host's turn; every step's result is on the host "
                     "before the timed region ends); 0: await each step's result before enqueuing the next (rounds 1-3)")
+    ap.add_argument("--inflight", type=int, default=2, help="forwards in flight (with --graph 1 and resident inputs; 1: rounds 1-3): 2 (default) captures the forward twice (two sets of "
+                    "buffers) and replays step i on HIP stream i %% 2, so the latency-bound tail of step i (support head, mask decoder, search: ~2.7 ms of small "
+                    "kernels) runs beside the encoder GEMMs of step i + 1; every step's result still reaches the host inside the timed region")
     ap.add_argument("--rehearse-rccl", type=int, default=0, help="1 (with --gpus 1): run the N > 1 code path on a ONE-rank nccl (= RCCL) group - process-group "
                     "init with device_id, barrier, query all-gather, list gather, max-reduce of the time, the `rccl` record - the most of the multi-GPU "
                     "path one GPU can execute (tests); the line still says n_gpus 1")
@@ -270,7 +274,7 @@ def main():
     import torch.distributed as dist
 
     from cor_amd import engine, ops, retrieval, utils
-    overlap = bool(args.graph) if args.overlap < 0 else bool(args.overlap)
+    overlap = {0: False, 1: "one_chain", 2: True}[(2 if args.graph else 0) if args.overlap < 0 else args.overlap]   # True: the two SigLIP towers as two chains
     engine.OVERLAP_BRANCHES = overlap and not args.graph   # eager steps; the captured graph takes it as an argument
     from cor_amd.lib.build_model import build_model_with_query_support_feat
 
@@ -295,13 +299,23 @@ def main():
         h2d.stage(host_batch)
 
     graphed, launch_mode = None, "eager ctypes launches"     # (captured BEFORE the process group exists: no RCCL host threads beside the capture)
+    names = ("query_image_inputs", "support_image_inputs", "change_text_inputs", "support_mask_inputs")
+    pipe = None                                          # --inflight > 1: cor_amd's ForwardPipeline (N captured forwards on N streams)
     if args.graph:
         try:
-            graphed = model.capture(**batch, multimask_output=mm, overlap_branches=overlap)
+            if args.inflight > 1 and not args.host_inputs:
+                pipe = model.capture_pipeline(**batch, multimask_output=mm, depth=args.inflight, overlap_branches=overlap)
+                graphed = pipe.slots[0][0]
+            else:
+                graphed = model.capture(**batch, multimask_output=mm, overlap_branches=overlap)
             if not args.host_inputs:                     # resident inputs: the batch IS the graph's input buffers (no per-step D2D copy)
-                batch = dict(zip(("query_image_inputs", "support_image_inputs", "change_text_inputs", "support_mask_inputs"), graphed.static_in))
+                batch = dict(zip(names, graphed.static_in))
             launch_mode = "hipGraph replay of the forward (model.capture" + (", support branch as a parallel graph branch" if overlap else "") + "); similarity search eager"
+            if pipe is not None:
+                launch_mode += (f"; {args.inflight} forwards in flight (model.capture_pipeline: step i replays captured graph i % {args.inflight}, which has its own "
+                                f"buffers, on stream i % {args.inflight}, followed there by its search and the lists' copy to the host)")
         except Exception as e:                           # noqa: BLE001 - the bench must still produce its line
+            graphed, pipe = None, None
             launch_mode = f"eager ctypes launches (graph capture failed: {type(e).__name__}: {e})"
 
     rehearse = bool(args.rehearse_rccl) and world == 1
@@ -318,15 +332,19 @@ def main():
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     multi = world > 1 or rehearse                        # the collective code path runs
 
+    def search(out):
+        # defer: the lists' device-to-host copy is enqueued behind an event; the host merge of step i runs after step i + 1 is enqueued
+        return retrieval.distributed_search(out[2][:, 0], shard, args.topk, max_local=B, timing=timing, always_collective=rehearse, defer=True)   # (awaited at once under --defer 0)
+
     def step():
+        if pipe is not None:                             # every slot's input buffers hold the synthetic batch (resident inputs)
+            return pipe.submit(None, then=search)[1]
         if h2d is not None:
             b = h2d.take()
             h2d.stage(host_batch)                      # next step's inputs start crossing PCIe now, on the copy stream
         else:
             b = batch
-        masks, emb, feat = graphed(**b) if graphed is not None else model(**b, multimask_output=mm)
-        # defer: the lists' device-to-host copy is enqueued behind an event; the host merge of step i runs after step i + 1 is enqueued
-        return retrieval.distributed_search(feat[:, 0], shard, args.topk, max_local=B, timing=timing, always_collective=rehearse, defer=True)   # (awaited at once under --defer 0)
+        return search(graphed(**b) if graphed is not None else model(**b, multimask_output=mm))
 
     def barrier():
         if multi:
@@ -343,15 +361,14 @@ def main():
     if graphed is None:
         ops.GEMM_PROFILE = prof                          # HIP events around every cor_gemm, on the launch stream
     t0 = time.perf_counter()
-    pend = None
+    pend = collections.deque()
+    keep = max(1, (args.inflight if pipe is not None else 1) - 1) if args.defer else 0   # results not yet awaited after an enqueue (1: step i - 1 is awaited once step i is enqueued)
     for _ in range(args.steps):
-        cur = step()                                     # forward + search of this step are enqueued ...
-        if not args.defer:
-            cur.result()
-        if pend is not None:
-            out = pend.result()                          # ... before the previous step's lists are awaited and merged on the host
-        pend = cur
-    out = pend.result()                                  # every step's top-k is materialised on the host inside the timed region
+        pend.append(step())                              # forward + search of this step are enqueued ...
+        while len(pend) > keep:
+            out = pend.popleft().result()                # ... before an earlier step's lists are awaited and merged on the host
+    while pend:
+        out = pend.popleft().result()                    # every step's top-k is materialised on the host inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     clk = clock.stop()
@@ -408,6 +425,7 @@ def main():
         }
         res["config"]["launch"] = launch_mode
         res["config"]["multimask_output"] = mm
+        res["config"]["forwards_in_flight"] = args.inflight if pipe is not None else 1
         res["config"]["results"] = ("every step's top-k lists reach the host inside the timed region; step i's lists are awaited and merged after step i + 1 "
                                     "is enqueued (pinned copy behind an event)") if args.defer else "each step's top-k lists are awaited before the next step is enqueued"
         res["roofline"]["events"] = events_from

@@ -426,8 +426,8 @@ OVERLAP_BRANCHES = False    # default of forward(overlap_branches=None); True: s
 _SIDE = {}
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, which=0):
+    key = (device.type, device.index, which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -445,12 +445,21 @@ def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_in
     if overlap_branches:
         # The support branch (SigLIP towers + ~100 tiny adapter/fusion kernels) is independent of the SAM encoder until
         # the mask decoder: enqueue it on a second HIP stream so its latency-bound kernels fill CUs the encoder leaves idle.
+        # The two towers are independent of each other as well: each is a CHAIN of ~110 small dependent kernels that advances only
+        # where the encoder's persistent GEMMs leave CUs free (2-3 kernels per big-kernel boundary), so one chain of both towers
+        # reached the support head ~1 ms after the encoder had finished; as two chains on two streams they end well inside it.
         main = torch.cuda.current_stream()
-        side = _side_stream(q_img.device)
+        side, side2 = _side_stream(q_img.device), _side_stream(q_img.device, 1)
         side.wait_stream(main)
+        side2.wait_stream(main)
+        two_chains = overlap_branches != "one_chain"       # "one_chain": both towers on one stream (rounds 2-3, kept for A/B runs: bench.py --overlap 1)
+        with torch.cuda.stream(side2 if two_chains else side):
+            txt = siglip_text(W, change_text_inputs.to(q_img.device), gcfg, T)
         with torch.cuda.stream(side):
             vis = siglip_vision(W, s_img, gcfg, T)
-            txt = siglip_text(W, change_text_inputs.to(q_img.device), gcfg, T)
+            if two_chains:
+                side.wait_stream(side2)
+                txt.record_stream(side)
             feat = support_head(W, vis, txt, s_mask, gcfg, mask_pooling, T)
         emb_tokens = sam_encoder(W, q_img, scfg, T)
         main.wait_stream(side)

@@ -1756,6 +1756,43 @@ def test_graph_captured_forward_equals_eager(mode):
         g(**b0)
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_forward_pipeline_equals_single_forwards(depth):
+    """model.capture_pipeline(): `depth` captured forwards on `depth` streams, consecutive submits overlapping on the GPU (bench.py
+    --inflight 2). Twelve submits of three alternating batches, NO host synchronisation in between, every slot's outputs cloned by
+    `then` on the slot's stream: each equals the eager forward of its batch bit for bit; the in-place input route (next_inputs)
+    too; the event marks the completion of the submit's work."""
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    from cor_amd import utils
+    model = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskAdapterPooling")
+    utils.randomize_parameters(model, seed=5)
+    model = model.to(DEV).eval()
+    model.compute_dtype = BF16
+    names = ("query_image_inputs", "support_image_inputs", "change_text_inputs", "support_mask_inputs")
+    batches = [utils.synthetic_batch(2, torch.device(DEV), seed=s) for s in (0, 1, 2)]
+    want = [[t.clone() for t in model(**b, multimask_output=True)] for b in batches]
+    pipe = model.capture_pipeline(**batches[0], multimask_output=True, depth=depth)
+    assert len(pipe.slots) == depth and len({st.cuda_stream for _, st in pipe.slots}) == depth
+    clone = lambda out: [t.clone() for t in out]                      # noqa: E731 (enqueued on the slot's stream, behind the replay)
+    got = [pipe.submit([batches[n % 3][k] for k in names], then=clone) for n in range(12)]
+    got[-1][2].synchronize()
+    torch.cuda.synchronize()
+    for n, (_, res, ev) in enumerate(got):
+        assert ev.query()
+        for a, b in zip(res, want[n % 3]):
+            assert torch.equal(a, b), n
+    for n in range(2 * depth):                                        # inputs written in place into the next slot's buffers
+        for dst, k in zip(pipe.next_inputs(), names):
+            dst.copy_(batches[(n + 1) % 3][k])
+        got.append(pipe.submit(None, then=clone))
+    torch.cuda.synchronize()
+    for n, (_, res, _) in enumerate(got[12:]):
+        for a, b in zip(res, want[(n + 1) % 3]):
+            assert torch.equal(a, b), n
+    with pytest.raises(ValueError):
+        model.capture_pipeline(**batches[0], depth=0)
+
+
 def test_distributed_search_on_a_one_rank_rccl_group():
     """The multi-rank retrieval path (query all-gather, shard search over all slots, packed-list gather, host merge) on the REAL backend:
     a one-rank `nccl` (= RCCL) process group on this box's GPU with always_collective=True. One rank moves nothing over xGMI, but
