@@ -363,12 +363,15 @@ def main():
     t0 = time.perf_counter()
     pend = collections.deque()
     keep = max(1, (args.inflight if pipe is not None else 1) - 1) if args.defer else 0   # results not yet awaited after an enqueue (1: step i - 1 is awaited once step i is enqueued)
+    done_at = []                                         # host time at which each step's merged top-k was in hand
     for _ in range(args.steps):
         pend.append(step())                              # forward + search of this step are enqueued ...
         while len(pend) > keep:
             out = pend.popleft().result()                # ... before an earlier step's lists are awaited and merged on the host
+            done_at.append(time.perf_counter() - t0)
     while pend:
         out = pend.popleft().result()                    # every step's top-k is materialised on the host inside the timed region
+        done_at.append(time.perf_counter() - t0)
     barrier()
     dt = time.perf_counter() - t0
     clk = clock.stop()
@@ -430,6 +433,7 @@ def main():
                                     "is enqueued (pinned copy behind an event)") if args.defer else "each step's top-k lists are awaited before the next step is enqueued"
         res["roofline"]["events"] = events_from
         res["clock"] = clk
+        res["step_done_ms"] = [round(t * 1e3, 2) for t in done_at]   # with two forwards in flight the first result arrives late, then one per steady-state interval
         if multi:
             res["rccl"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), **coll,
                                note="rank 0's means over the timed steps; device events on the launch stream under nccl (= RCCL), host clocks under the "

@@ -433,42 +433,35 @@ def _side_stream(device, which=0):
     return _SIDE[key]
 
 
-def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
-            multimask_output=True, return_aux=False, overlap_branches=None):
-    """ref: lib/sam_with_sup_branch.py:57-104. overlap_branches (None = module default OVERLAP_BRANCHES): per-call choice."""
-    if overlap_branches is None:
-        overlap_branches = OVERLAP_BRANCHES
-    B = query_image_inputs.shape[0]
-    q_img = query_image_inputs.to(F32).contiguous()
+def forward_support(W, gcfg, mask_pooling, T, support_image_inputs, change_text_inputs, support_mask_inputs, two_chains=True, text_stream=None):
+    """The support branch on the CURRENT stream (ref: lib/sam_with_sup_branch.py:79-80 -> lib/support_branch.py:56-87): SigLIP towers,
+    mask adapter, fusion, dim_proj -> comb_support_feat fp32 [B,256]. two_chains: the text tower on one more stream (the towers are
+    independent: each is a CHAIN of ~110 small dependent kernels, and a chain advances only where the encoder's persistent GEMMs
+    leave CUs free, 2-3 kernels per big-kernel boundary). text_stream: a stream the CALLER has already forked from the stream its own
+    stream was forked from (a fork of a forked stream inside a graph capture crashed hipGraph's capture_end on ROCm 7.0: forks stay flat)."""
     s_img = support_image_inputs.to(F32).contiguous()
     s_mask = support_mask_inputs.to(F32).contiguous()
-    if overlap_branches:
-        # The support branch (SigLIP towers + ~100 tiny adapter/fusion kernels) is independent of the SAM encoder until
-        # the mask decoder: enqueue it on a second HIP stream so its latency-bound kernels fill CUs the encoder leaves idle.
-        # The two towers are independent of each other as well: each is a CHAIN of ~110 small dependent kernels that advances only
-        # where the encoder's persistent GEMMs leave CUs free (2-3 kernels per big-kernel boundary), so one chain of both towers
-        # reached the support head ~1 ms after the encoder had finished; as two chains on two streams they end well inside it.
-        main = torch.cuda.current_stream()
-        side, side2 = _side_stream(q_img.device), _side_stream(q_img.device, 1)
-        side.wait_stream(main)
-        side2.wait_stream(main)
-        two_chains = overlap_branches != "one_chain"       # "one_chain": both towers on one stream (rounds 2-3, kept for A/B runs: bench.py --overlap 1)
-        with torch.cuda.stream(side2 if two_chains else side):
-            txt = siglip_text(W, change_text_inputs.to(q_img.device), gcfg, T)
-        with torch.cuda.stream(side):
-            vis = siglip_vision(W, s_img, gcfg, T)
-            if two_chains:
-                side.wait_stream(side2)
-                txt.record_stream(side)
-            feat = support_head(W, vis, txt, s_mask, gcfg, mask_pooling, T)
-        emb_tokens = sam_encoder(W, q_img, scfg, T)
-        main.wait_stream(side)
-        feat.record_stream(main)
-    else:
-        emb_tokens = sam_encoder(W, q_img, scfg, T)                                        # :76
-        vis = siglip_vision(W, s_img, gcfg, T)                                             # :79 ->
-        txt = siglip_text(W, change_text_inputs, gcfg, T)
-        feat = support_head(W, vis, txt, s_mask, gcfg, mask_pooling, T)                    # [B,256]
+    if not two_chains:
+        vis = siglip_vision(W, s_img, gcfg, T)
+        txt = siglip_text(W, change_text_inputs.to(s_img.device), gcfg, T)
+        return support_head(W, vis, txt, s_mask, gcfg, mask_pooling, T)
+    cur = torch.cuda.current_stream()
+    side2 = text_stream
+    if side2 is None:
+        side2 = _side_stream(s_img.device, 1)
+        side2.wait_stream(cur)
+    with torch.cuda.stream(side2):
+        txt = siglip_text(W, change_text_inputs.to(s_img.device), gcfg, T)
+    vis = siglip_vision(W, s_img, gcfg, T)
+    cur.wait_stream(side2)
+    txt.record_stream(cur)
+    return support_head(W, vis, txt, s_mask, gcfg, mask_pooling, T)
+
+
+def forward_decode(W, scfg, T, emb_tokens, feat, multimask_output=True, return_aux=False):
+    """Mask decoder + the API's output layout (ref: lib/sam_with_sup_branch.py:82-104) from the encoder's tokens fp32 [B*4096,256]
+    and comb_support_feat fp32 [B,256]."""
+    B = feat.shape[0]
     final, iou, best, masks_all, _ = mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=return_aux)   # :82-100
     g = scfg["img"] // scfg["patch"]
     emb = ops.tokens_to_nchw(emb_tokens, B, g * g, scfg["out"]).view(B, scfg["out"], g, g)
@@ -476,3 +469,31 @@ def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_in
     if return_aux:
         return out + (dict(masks=masks_all, iou=iou, best=best),)
     return out
+
+
+def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
+            multimask_output=True, return_aux=False, overlap_branches=None):
+    """ref: lib/sam_with_sup_branch.py:57-104. overlap_branches (None = module default OVERLAP_BRANCHES): per-call choice."""
+    if overlap_branches is None:
+        overlap_branches = OVERLAP_BRANCHES
+    q_img = query_image_inputs.to(F32).contiguous()
+    if overlap_branches:
+        # The support branch (SigLIP towers + ~100 tiny adapter/fusion kernels) is independent of the SAM encoder until
+        # the mask decoder: enqueue it on a second HIP stream so its latency-bound kernels fill CUs the encoder leaves idle.
+        # "one_chain": both towers on that stream (rounds 2-3, kept for A/B runs: bench.py --overlap 1); otherwise two chains.
+        main = torch.cuda.current_stream()
+        side, side2 = _side_stream(q_img.device), None
+        side.wait_stream(main)
+        if overlap_branches != "one_chain":
+            side2 = _side_stream(q_img.device, 1)
+            side2.wait_stream(main)
+        with torch.cuda.stream(side):
+            feat = forward_support(W, gcfg, mask_pooling, T, support_image_inputs, change_text_inputs, support_mask_inputs,
+                                   two_chains=side2 is not None, text_stream=side2)
+        emb_tokens = sam_encoder(W, q_img, scfg, T)                                        # :76
+        main.wait_stream(side)
+        feat.record_stream(main)
+    else:
+        emb_tokens = sam_encoder(W, q_img, scfg, T)
+        feat = forward_support(W, gcfg, mask_pooling, T, support_image_inputs, change_text_inputs, support_mask_inputs, two_chains=False)
+    return forward_decode(W, scfg, T, emb_tokens, feat, multimask_output, return_aux)

@@ -205,3 +205,4 @@ class ForwardPipeline:
                 ev.record(st)
         self.last[i] = ev
         return out, res, ev
+

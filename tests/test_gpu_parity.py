@@ -1851,6 +1851,7 @@ def test_bench_contract_smoke(tmp_path):
     assert rec["fp32_mode_topk_entries"] == 30 and rec["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0, rec
     assert d["fp32_mode_topk_index_mismatches_vs_cpu_oracle"] == 0 and d["cpu_oracle_recall_at_1"] == 1.0
     assert "clock" in d and d["config"]["multimask_output"] is True and "awaited and merged after step i + 1" in d["config"]["results"]
+    assert d["config"]["forwards_in_flight"] == 2 and "capture_pipeline" in d["config"]["launch"] and len(d["step_done_ms"]) == 2   # the default
 
 
 def test_bench_multi_rank_code_path_on_a_one_rank_rccl_group(tmp_path):

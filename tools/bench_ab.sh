@@ -11,7 +11,7 @@ for r in $(seq 1 "$rounds"); do
     python - "$out/line.json" "$v" >> "$out/bench_ab.jsonl" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-print(json.dumps(dict(flags=sys.argv[2], value=round(d["value"], 1), ms_per_step=round(d["ms_per_step"], 3), sclk_mhz=round(d["clock"]["sclk_mhz_mean"]))))
+print(json.dumps(dict(flags=sys.argv[2], value=round(d["value"], 1), ms_per_step=round(d["ms_per_step"], 3), sclk_mhz=round(d["clock"]["sclk_mhz_mean"]), first_ms=d["step_done_ms"][0], steady_ms=round((d["step_done_ms"][-2] - d["step_done_ms"][1]) / (len(d["step_done_ms"]) - 3), 3), last_ms=round(d["step_done_ms"][-1] - d["step_done_ms"][-2], 2))))
 PY
     tail -1 "$out/bench_ab.jsonl"
   done
