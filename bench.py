@@ -42,8 +42,8 @@ sys.path.insert(0, ROOT)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
     ap.add_argument("--gallery", type=int, default=100000, help="total gallery rows (BASELINE metric: 100k-region gallery)")
     ap.add_argument("--topk", type=int, default=10)

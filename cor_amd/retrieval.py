@@ -182,7 +182,7 @@ def distributed_search(local_queries: torch.Tensor, shard: GalleryShard, k: int,
     cdev = torch.device("cpu") if host_coll else dev
     block = torch.zeros((cap + 1, C), dtype=torch.float32, device=cdev)
     block[:b_local] = q.to(cdev)
-    block[cap, 0] = float(b_local)
+    block[cap, :1].fill_(float(b_local))                         # (a fill kernel; `block[cap, 0] = x` copies a host scalar: the host would wait for the stream)
     allb = torch.empty((world * (cap + 1), C), dtype=torch.float32, device=cdev)
     marks = _Marks(dev, host_coll) if timing is not None else None
     if marks:

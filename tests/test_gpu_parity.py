@@ -1825,6 +1825,25 @@ def test_distributed_search_on_a_one_rank_rccl_group():
         t = retrieval.resolve_timing(timing)
         assert t["calls"] == 1 and t["collective_ms"] > 0 and t["search_ms"] > 0 and dist.get_backend() == "nccl"
         _note(name="distributed_search_one_rank_rccl", **t)
+        # the deferred collective path never makes the HOST wait for the stream (round 4: `block[cap, 0] = float(n)` copied a host scalar
+        # behind the forward, so every rank idled its GPU through the enqueue of the collectives): behind ~100 ms of queued GPU work the
+        # call returns at once, for both forms of the second collective
+        import time
+        a = torch.randn((8192, 8192), device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(16):
+            a @ a
+        t1 = time.perf_counter()
+        p1 = retrieval.distributed_search(Q, shard, 10, max_local=8, always_collective=True, defer=True)
+        p2 = retrieval.distributed_search(Q, shard, 10, max_local=8, dst=None, always_collective=True, defer=True)
+        t2 = time.perf_counter()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        assert (t3 - t0) > 0.05 and (t2 - t1) < 0.4 * (t3 - t0), (t1 - t0, t2 - t1, t3 - t2)
+        for p_ in (p1, p2):
+            assert torch.equal(p_.result()[1], i0.cpu())
+        _note(name="distributed_search_host_time_behind_queued_work", queued_gpu_ms=(t3 - t0) * 1e3, host_ms_two_calls=(t2 - t1) * 1e3)
     finally:
         dist.destroy_process_group()
 
