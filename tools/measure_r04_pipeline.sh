@@ -18,4 +18,4 @@ echo "driver form done"
 timeout -k 10 400 python3 bench.py --gpus 2 --backend gloo --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err; echo "gloo2 rc=$?"
 timeout -k 10 300 python3 bench.py --multimask 0 --no-cpu-baseline > $O/bench_mm0.json 2>/dev/null; echo "mm0 rc=$?"
 timeout -k 10 300 python3 bench.py --sam sam_large --siglip ViT-L-16-SigLIP-384 --batch 64 --no-cpu-baseline > $O/bench_L.json 2>/dev/null; echo "L rc=$?"
-timeout -k 10 300 python3 bench.py --rehearse-rccl 1 --no-cpu-baseline > $O/bench_rccl1.json 2>/dev/null; echo "rccl1 rc=$?"
+timeout -k 10 300 python3 bench.py --rehearse-rccl 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_rccl1.json 2>/dev/null; echo "rccl1 rc=$?"
