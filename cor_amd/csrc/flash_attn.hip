@@ -63,6 +63,13 @@ __device__ __forceinline__ uint4 pack8(float f0, float f1, float f2, float f3, f
   return u;
 }
 
+// acc + both bf16 halves of a packed pair (v_dot2c_f32_bf16 against (1, 1)): the row sum of P costs one instruction per TWO keys; it
+// is taken over the bf16-rounded P, the values the PV product uses
+__device__ __forceinline__ float sum2_bf16(uint32_t pair, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pair), __builtin_bit_cast(bf16x2_t, 0x3f803f80u), acc, false);
+}
+__device__ __forceinline__ float max3f_(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 // A fragment (rows j of an fp32 [rows, 64] table, k-step c) converted to bf16
 __device__ __forceinline__ uint4 table_frag(const float* tbl, int j, int c, int h) {
   const float* p = tbl + (long)j * 64 + 16 * c + 8 * h;
@@ -656,16 +663,23 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
     }
-    float mloc = -INFINITY;
+    float mloc;
     {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const float x0 = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]), x1 = fmaf(s[kb][e + 1], a.scale_log2, wreg[kb][e + 1]);
-          s[kb][e] = x0; s[kb][e + 1] = x1;
-          mloc = fmaxf(mloc, fmaxf(x0, x1));
+        for (int e = 0; e < 16; ++e) s[kb][e] = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]);
+      // tile maximum of the lane's 32 scores as a tree of v_max3_f32: 16 instructions (a running max3 chain came out as 17 v_max + 8 v_max3)
+      float m4[4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int e = 8 * g;
+          const float t0 = max3f_(s[kb][e], s[kb][e + 1], s[kb][e + 2]), t1 = max3f_(s[kb][e + 3], s[kb][e + 4], s[kb][e + 5]);
+          m4[kb * 2 + g] = max3f_(max3f_(t0, t1, s[kb][e + 6]), s[kb][e + 7], -INFINITY);
         }
+      mloc = fmaxf(max3f_(m4[0], m4[1], m4[2]), m4[3]);
 #pragma unroll
       for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -710,16 +724,16 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       f32x16 p;
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub);
-      // row sums: this lane's 16 keys of the block (the other lane half holds the other 16)
-      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
-      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[kb][1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
+      // row sums: this lane's 16 keys of the block (the other lane half holds the other 16), two keys per instruction
+      lsum[1] = sum2_bf16(pf[kb][0].y, sum2_bf16(pf[kb][0].x, lsum[1])); lsum[2] = sum2_bf16(pf[kb][0].w, sum2_bf16(pf[kb][0].z, lsum[2]));
+      lsum[1] = sum2_bf16(pf[kb][1].y, sum2_bf16(pf[kb][1].x, lsum[1])); lsum[2] = sum2_bf16(pf[kb][1].w, sum2_bf16(pf[kb][1].z, lsum[2]));
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {         // 1 MFMA : 11 VALU
+    for (int i = 0; i < 8; ++i) {         // 1 MFMA : 12 VALU (32 sub + 32 exp2 + 16 cvt_pk + 16 dot2)
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     c3 = c3p1;
