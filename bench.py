@@ -258,6 +258,10 @@ def main():
         raise SystemExit(spawn_ranks(detail, sys.argv[1:]))
     if args.launch_check:
         return launch_check(args)
+    # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). With two forwards in flight the slots' streams and their
+    # graph branches SHARE queues, which staggers the two forwards (one's encoder beside the other's tail); with 8 or 16 queues they run in
+    # lockstep and a step takes 46.3 instead of 42.6 ms (profiles/r04_pipeline_ab.jsonl, ab10): the measured configuration is pinned.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -429,6 +433,7 @@ def main():
         res["config"]["launch"] = launch_mode
         res["config"]["multimask_output"] = mm
         res["config"]["forwards_in_flight"] = args.inflight if pipe is not None else 1
+        res["config"]["hip_hw_queues"] = int(os.environ["GPU_MAX_HW_QUEUES"])
         res["config"]["results"] = ("every step's top-k lists reach the host inside the timed region; step i's lists are awaited and merged after step i + 1 "
                                     "is enqueued (pinned copy behind an event)") if args.defer else "each step's top-k lists are awaited before the next step is enqueued"
         res["roofline"]["events"] = events_from
