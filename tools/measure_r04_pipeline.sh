@@ -7,7 +7,10 @@ O=$R/gpurun_out/m5; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/prof_bench.json 2>/dev/null || exit 1
 echo "kernel trace (two forwards in flight) done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_eager -- python3 $R/bench.py --steps 4 --warmup 1 --graph 0 --overlap 0 --no-cpu-baseline > $O/prof_eager.json 2>/dev/null || exit 1
+echo "kernel trace (eager, one stream) done"
 cd $R
+timeout -k 10 200 python3 tools/attn_bench.py 32 > $O/attn_bench.jsonl 2>/dev/null || exit 1
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"; grep '^{"metric"' $O/bench.json | cut -c1-200
 : > $O/driver_form.jsonl
