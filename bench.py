@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--inflight", type=int, default=2, help="forwards in flight (with --graph 1 and resident inputs; 1: rounds 1-3): 2 (default) captures the forward twice (two sets of "
                     "buffers) and replays step i on HIP stream i %% 2, so the latency-bound tail of step i (support head, mask decoder, search: ~2.7 ms of small "
                     "kernels) runs beside the encoder GEMMs of step i + 1; every step's result still reaches the host inside the timed region")
+    ap.add_argument("--pending", type=int, default=-1, help="results left un-awaited after an enqueue (-1: forwards in flight - 1, at least 1)")
     ap.add_argument("--rehearse-rccl", type=int, default=0, help="1 (with --gpus 1): run the N > 1 code path on a ONE-rank nccl (= RCCL) group - process-group "
                     "init with device_id, barrier, query all-gather, list gather, max-reduce of the time, the `rccl` record - the most of the multi-GPU "
                     "path one GPU can execute (tests); the line still says n_gpus 1")
@@ -366,7 +367,7 @@ def main():
         ops.GEMM_PROFILE = prof                          # HIP events around every cor_gemm, on the launch stream
     t0 = time.perf_counter()
     pend = collections.deque()
-    keep = max(1, (args.inflight if pipe is not None else 1) - 1) if args.defer else 0   # results not yet awaited after an enqueue (1: step i - 1 is awaited once step i is enqueued)
+    keep = (args.pending if args.pending >= 0 else max(1, (args.inflight if pipe is not None else 1) - 1)) if args.defer else 0   # results not yet awaited after an enqueue (1: step i - 1 is awaited once step i is enqueued)
     done_at = []                                         # host time at which each step's merged top-k was in hand
     for _ in range(args.steps):
         pend.append(step())                              # forward + search of this step are enqueued ...
