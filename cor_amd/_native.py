@@ -49,6 +49,7 @@ SIGNATURES = {
     "cor_upscale_shuffle": [_p, _i, _p, _p, _p, _f, _i, _p, _i, _i, _i, _i, _i, _p],
     "cor_upscale_hyper": [_p, _i, _p, _p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _p],
     "cor_iou_select": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "cor_decoder_heads": [_p, _p, _p, _p, _p, _i, _p, _p, _i, _p],
     "cor_mask_prob_minmax": [_p, _p, _i, _i, _p],
     "cor_resize_binarize": [_p, _p, _i, _i, _i, _i, _i, _f, _p],
     "cor_resize_gray": [_p, _p, _i, _i, _i, _i, _i, _p],

@@ -348,7 +348,95 @@ __global__ void iou_select_kernel(const float* iou, const float* hyper, int B, i
   for (int c = threadIdx.x; c < C; c += blockDim.x) hyper_sel[(long)b * C + c] = hyper[((long)b * Kall + k_off + bi) * C + c];
 }
 
+// The five output MLPs of the mask decoder (four hyper-network MLPs on mask tokens 1..4, the IoU head on token 0; each 256 -> 256 -> 256 ->
+// 32 | 4 with ReLU) in ONE launch: as 15 GEMM launches on 6 tokens per image they were 143 us of pure launch latency on the step's critical
+// path. Block = (group of NS samples, MLP m); thread n owns output feature n of the two hidden layers: it streams row n of the weight
+// (16-byte loads; the 128 KB of a layer come out of L2) against the NS activation vectors in LDS (broadcast reads) - fp32 FMA chains over
+// k = 0..255 in order, so a sample's result does not depend on the batch it is in. Hidden activations are rounded to the operand type
+// like the GEMM outputs they replace.
+constexpr int DH_NS = 8;
+template <typename TW> __device__ __forceinline__ void dh_row8(const TW* w, float (&f)[8]);
+template <> __device__ __forceinline__ void dh_row8<bf16_t>(const bf16_t* w, float (&f)[8]) {
+  const uint4 u = *(const uint4*)w;
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u); f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u); f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void dh_row8<float>(const float* w, float (&f)[8]) {
+  const f32x4 a = *(const f32x4*)w, b = *(const f32x4*)(w + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+template <typename TW>
+__device__ __forceinline__ void dh_dot(const TW* wrow, const float (*x)[256], float (&acc)[DH_NS]) {
+#pragma unroll 4
+  for (int k = 0; k < 256; k += 8) {
+    float w[8];
+    dh_row8<TW>(wrow + k, w);
+#pragma unroll
+    for (int s = 0; s < DH_NS; ++s) {
+      const f32x4 a = *(const f32x4*)&x[s][k], b = *(const f32x4*)&x[s][k + 4];
+      acc[s] = fmaf(w[0], a[0], acc[s]); acc[s] = fmaf(w[1], a[1], acc[s]); acc[s] = fmaf(w[2], a[2], acc[s]); acc[s] = fmaf(w[3], a[3], acc[s]);
+      acc[s] = fmaf(w[4], b[0], acc[s]); acc[s] = fmaf(w[5], b[1], acc[s]); acc[s] = fmaf(w[6], b[2], acc[s]); acc[s] = fmaf(w[7], b[3], acc[s]);
+    }
+  }
+}
+template <typename TW>
+__global__ void __launch_bounds__(256) decoder_heads_kernel(const TW* hs, const TW* w01, const float* b01, const TW* w2, const float* b2,
+                                                            float* hyper, float* iou, int B) {
+  __shared__ __attribute__((aligned(16))) float xa[DH_NS][256], xb[DH_NS][256];
+  const int tid = threadIdx.x, m = blockIdx.y, s0 = blockIdx.x * DH_NS;
+  const int tok = m < 4 ? 1 + m : 0;
+#pragma unroll
+  for (int s = 0; s < DH_NS; ++s) xa[s][tid] = s0 + s < B ? ld<TW>(hs + ((long)(s0 + s) * 6 + tok) * 256 + tid) : 0.f;
+  __syncthreads();
+#pragma unroll 1
+  for (int layer = 0; layer < 2; ++layer) {
+    const float (*xi)[256] = layer == 0 ? xa : xb;
+    float (*xo)[256] = layer == 0 ? xb : xa;
+    float acc[DH_NS];
+    const float bias = b01[(m * 2 + layer) * 256 + tid];
+#pragma unroll
+    for (int s = 0; s < DH_NS; ++s) acc[s] = bias;
+    dh_dot<TW>(w01 + ((long)(m * 2 + layer) * 256 + tid) * 256, xi, acc);
+#pragma unroll
+    for (int s = 0; s < DH_NS; ++s) {
+      float v = fmaxf(acc[s], 0.f);
+      if (sizeof(TW) == 2) v = bf2f(f2bf(v));
+      xo[s][tid] = v;
+    }
+    __syncthreads();
+  }
+  const int nout = m < 4 ? 32 : 4;
+  if (tid < nout) {
+    const int row = (m < 4 ? 32 * m : 128) + tid;
+    float acc[DH_NS];
+#pragma unroll
+    for (int s = 0; s < DH_NS; ++s) acc[s] = b2[row];
+    dh_dot<TW>(w2 + (long)row * 256, xa, acc);
+#pragma unroll
+    for (int s = 0; s < DH_NS; ++s)
+      if (s0 + s < B) {
+        if (m < 4) hyper[(long)(s0 + s) * 128 + row] = acc[s];
+        else iou[(long)(s0 + s) * 4 + tid] = acc[s];
+      }
+  }
+}
+
 }  // namespace
+
+extern "C" int cor_decoder_heads(const void* hs, const void* w01, const float* b01, const void* w2, const float* b2, int dtype, float* hyper,
+                                 float* iou, int B, void* stream) {
+  if (!hs || !w01 || !b01 || !w2 || !b2 || !hyper || !iou || B <= 0) return COR_EINVAL;
+  if ((((uintptr_t)hs | (uintptr_t)w01 | (uintptr_t)w2) & 15) != 0) return COR_EINVAL;
+  const dim3 grid(cdiv(B, DH_NS), 5);
+  if (dtype == COR_BF16)
+    hipLaunchKernelGGL(decoder_heads_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hs, (const bf16_t*)w01, b01, (const bf16_t*)w2, b2, hyper, iou, B);
+  else if (dtype == COR_F32)
+    hipLaunchKernelGGL(decoder_heads_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)hs, (const float*)w01, b01, (const float*)w2, b2, hyper, iou, B);
+  else
+    return COR_ENOSUPPORT;
+  COR_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int cor_bilinear(const float* x, float* out, int planes, int H, int W, int OH, int OW, int clamp01, void* stream) {
   if (!x || !out || planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return COR_EINVAL;

@@ -379,6 +379,21 @@ def similarity_topk(Q, G, k, g_offset=0, flags=0):
     return scores, idx
 
 
+def decoder_heads(hs, w01, b01, w2, b2):
+    """The mask decoder's five output MLPs in one launch (cor_decoder_heads). hs [B*6,256] in the weights' dtype ->
+    (hyper f32 [B,4,32], iou f32 [B,4])."""
+    _dev(hs, w01, b01, w2, b2)
+    assert hs.is_contiguous() and hs.dim() == 2 and hs.shape[1] == 256 and hs.shape[0] % 6 == 0 and hs.dtype == w01.dtype == w2.dtype
+    assert tuple(w01.shape) == (5, 2, 256, 256) and tuple(b01.shape) == (5, 2, 256) and tuple(w2.shape) == (132, 256) and tuple(b2.shape) == (132,)
+    assert w01.is_contiguous() and w2.is_contiguous() and b01.is_contiguous() and b2.is_contiguous() and b01.dtype == b2.dtype == torch.float32
+    B = hs.shape[0] // 6
+    hyper = torch.empty((B, 4, 32), dtype=torch.float32, device=hs.device)
+    iou = torch.empty((B, 4), dtype=torch.float32, device=hs.device)
+    nat.check(_lib().cor_decoder_heads(hs.data_ptr(), w01.data_ptr(), b01.data_ptr(), w2.data_ptr(), b2.data_ptr(), _dt(hs), hyper.data_ptr(),
+                                       iou.data_ptr(), B, _s()), "cor_decoder_heads")
+    return hyper, iou
+
+
 def mask_prob_minmax(logits):
     """sigmoid + per-sample min-max normalisation of mask logits [B,1,H,W] (utils/vailder.py:426-430)."""
     _dev(logits)

@@ -189,6 +189,14 @@ int cor_upscale_hyper(const void* x, int dtype, const float* w, const float* bia
 int cor_iou_select(const float* iou, const float* hyper, int B, int Kall, int k_off, int Ksel, int C, long long* best,
                    float* hyper_sel, void* stream);
 
+/* The decoder's five output MLPs in one launch: hyper-network MLP i (i = 0..3) on mask token 1+i -> hyper[b, i, 0:32], IoU head on token 0
+ * -> iou[b, 0:4]; each Linear(256,256) ReLU Linear(256,256) ReLU Linear(256, 32 | 4). hs [B,6,256] in `dtype` (COR_F32 | COR_BF16, the
+ * weights' type too); w01 [5,2,256,256] (MLP, layer, out, in; MLP 4 = IoU head), b01 [5,2,256] fp32, w2 [132,256] (rows 32 i + c of
+ * hyper MLP i, rows 128..131 of the IoU head), b2 [132] fp32. fp32 accumulation over k in order; hidden activations rounded to `dtype`.
+ * ref: mask_decoder.py:123-140 (output_hypernetworks_mlps, iou_prediction_head), :147-167 (MLP). */
+int cor_decoder_heads(const void* hs, const void* w01, const float* b01, const void* w2, const float* b2, int dtype, float* hyper,
+                      float* iou, int B, void* stream);
+
 /* ---- inference harness (mask post-processing, metrics) ---------------------------------------------------------------- */
 
 /* out = (sigmoid(x) - min) / (max - min + 1e-8), min/max per sample. ref: utils/vailder.py:426-430. */

@@ -574,6 +574,41 @@ def test_sam_encoder_vs_reference_golden(tag):
     report(f"sam_encoder_golden_{tag}", y, g["y"], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("mode", [F32, BF16])
+@pytest.mark.parametrize("B", [1, 5, 32])
+def test_decoder_heads_one_launch_equals_the_gemm_path(mode, B):
+    """cor_decoder_heads (the decoder's five output MLPs in one launch) against the 15-GEMM path it replaces, same packed weights and
+    tokens: fp32 within 2e-5 of the scale (fp32 FMA chains vs the exact-fp32 MFMA), bf16 within the rounding of the hidden activations;
+    a sample's result does not depend on the batch it is in (bitwise)."""
+    ops, engine = _ops()
+    pk = packer(ocfg.random_state(dict(ocfg.mask_decoder_spec(), **ocfg.prompt_encoder_spec()), 3), mode)
+    engine.pack_mask_decoder(pk)
+    W = pk.W
+    gen = torch.Generator().manual_seed(B)
+    hs = (torch.randn((B * 6, 256), generator=gen) * 2).to(mode).to(DEV)
+    hyper, iou = ops.decoder_heads(hs, W["heads.w01"], W["heads.b01"], W["heads.w2"], W["heads.b2"])
+    hs3 = hs.view(B, 6 * 256)
+    p = "mask_decoder."
+    ref_h = torch.empty((B, 4, 32), dtype=F32, device=DEV)
+    for i in range(4):
+        m = f"{p}output_hypernetworks_mlps.{i}.layers."
+        a = engine._lin(W, m + "0.", hs3[:, (1 + i) * 256:(2 + i) * 256], mode, act=engine.ACT_RELU)
+        a = engine._lin(W, m + "1.", a, mode, act=engine.ACT_RELU)
+        engine._lin(W, m + "2.", a, F32, out=ref_h.view(B, 128)[:, 32 * i:32 * (i + 1)])
+    m = p + "iou_prediction_head.layers."
+    a = engine._lin(W, m + "0.", hs3[:, 0:256], mode, act=engine.ACT_RELU)
+    a = engine._lin(W, m + "1.", a, mode, act=engine.ACT_RELU)
+    ref_i = engine._lin(W, m + "2.", a, F32)
+    tol = 2e-5 if mode == F32 else 2e-2
+    for got, ref, name in ((hyper, ref_h, "hyper"), (iou, ref_i, "iou")):
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        _note(name=f"decoder_heads_{name}", mode=str(mode), B=B, max_abs_err=err, scale=scale)
+        assert err <= tol * max(scale, 1.0), (name, err, scale)
+    one_h, one_i = ops.decoder_heads(hs[6 * (B - 1):].contiguous(), W["heads.w01"], W["heads.b01"], W["heads.w2"], W["heads.b2"])
+    assert torch.equal(one_h[0], hyper[B - 1]) and torch.equal(one_i[0], iou[B - 1])
+
+
 def test_mask_decoder_vs_reference_golden():
     ops, engine = _ops()
     g = load("mask_decoder")
