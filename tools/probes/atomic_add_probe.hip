@@ -1,6 +1,6 @@
 // Bandwidth of non-returning fp32 atomic adds (global_atomic_add_f32, performed at L2) against a load-add-store pass over the same
 // 131072 x 768 fp32 matrix (the residual stream): is "fire and forget" residual accumulation an option for the GEMM epilogue?
-// hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -o atomic_add_probe atomic_add_probe.hip && ./atomic_add_probe
+// hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value -o /tmp/atomic_add_probe tools/probes/atomic_add_probe.hip && /tmp/atomic_add_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
