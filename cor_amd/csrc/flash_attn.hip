@@ -931,9 +931,8 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[c]), __builtin_bit_cast(bf16x8, qf[c]), s, 0, 0, 0);
-    float mloc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-#pragma unroll
-    for (int e = 4; e < 16; e += 4) mloc = fmaxf(mloc, fmaxf(fmaxf(s[e], s[e + 1]), fmaxf(s[e + 2], s[e + 3])));
+    float mloc = max3f_(max3f_(s[0], s[1], s[2]), max3f_(s[3], s[4], s[5]), max3f_(s[6], s[7], s[8]));   // 8 v_max3 / v_max instead of 15 v_max
+    mloc = fmaxf(max3f_(mloc, max3f_(s[9], s[10], s[11]), max3f_(s[12], s[13], s[14])), s[15]);
     mloc = fmaxf(mloc, other_half(mloc));               // block maximum of x - m for this query
     // reference update: always after the first block (m = its maximum), later only when a block maximum exceeds it by 2^8
     if (blk == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
@@ -953,10 +952,11 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
       f32x16 p;
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[e]);
-      lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);     // row sums on the VALU (see flash_fwd)
-      lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
       pf[1] = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
+      // row sums on the VALU, two keys per instruction on the packed pairs (see flash_global_pipe)
+      lsum[1] = sum2_bf16(pf[0].y, sum2_bf16(pf[0].x, lsum[1])); lsum[2] = sum2_bf16(pf[0].w, sum2_bf16(pf[0].z, lsum[2]));
+      lsum[1] = sum2_bf16(pf[1].y, sum2_bf16(pf[1].x, lsum[1])); lsum[2] = sum2_bf16(pf[1].w, sum2_bf16(pf[1].z, lsum[2]));
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
