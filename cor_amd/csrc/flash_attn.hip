@@ -794,6 +794,356 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Global SAM attention, 64 QUERIES PER WAVE at ONE wave per SIMD (round 5; the default when q arrives pre-scaled, i.e. the
+// engine's path). flash_global_pipe above runs two 32-query waves per SIMD; its two waves' matrix and vector work barely overlap
+// (stamps: a 64-key tile costs about the SUM of both waves' demands) and every K / V fragment is read from LDS once per 32 queries.
+// Here a wave owns one whole grid row of queries (64 = two 32-query blocks qb) and the whole 512-register file:
+//   * K(t+1) / V(t-1) fragments are read once per 64 queries (half the LDS reads, half the LDS-DMA issues per score);
+//   * q is pre-scaled (scale * log2 e folded into the qkv weight at pack time), so the column bias is the C OPERAND of the first
+//     score MFMA of each chain (accumulator start value = wreg, kept as f32x16): no vector instruction per score for scale + bias;
+//   * one instruction stream per SIMD: the 32 MFMAs of an iteration (PV(t-1): 16, QK(t+1): 16) are spread over the ~230 vector
+//     instructions of the softmax of S(t) in proportion (sched_group_barrier), so neither pipe waits for a partner wave's phase;
+//   * V ring of four (issued two iterations ahead, like K): one wave per SIMD has nothing else to hide a late tile.
+// Row bias: one LDS scalar per lane, q-block and tile, as above. Lazy rescale as above (one ballot for both q-blocks).
+// LDS = 32 KiB K ring + 32 KiB V ring + 4 x 16 KiB row-bias tables = 128 KiB: one block per CU.
+// DBG (probe builds of the timing ablations only; results are garbage when set): 1 no copies in the loop, 2 no wait / barrier,
+// 4 no fragment reads, 8 no exp2, 16 no tile maxima, 32 no PV MFMAs, 64 no score MFMAs
+template <typename TO, int DBG = 0>
+__global__ void __launch_bounds__(256, 1) flash_global_w64(const FlashArgs a) {   // 4 waves x 64 queries per block
+  constexpr int NW = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K_BYTES = 4 * TILE_B, V_BYTES = 4 * TILE_B, AUXW = 64 * 64 * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi0_ = xcd_remap(blockIdx.x, gridDim.x);
+  const int wi_ = a.rev ? (int)gridDim.x - 1 - wi0_ : wi0_;
+  const int qt_ = wi_ % a.nqt, hb_ = wi_ / a.nqt;
+  const int head = hb_ % a.H, b = hb_ / a.H;
+  constexpr int S = 64;
+  const int g2 = S * S;
+  const bf16_t* kvbase = a.q + (long)b * g2 * a.d3 + head * 64;
+  const int qh = qt_ * NW + wave;                       // the wave's grid row; query (qb, r) sits at column qw = 32 qb + r
+
+  u32x4 qf[2][4];                                       // B operands of every score MFMA: 128-bit values (they live in AGPRs)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const bf16_t* qp = a.q + ((long)b * g2 + qh * S + qb * 32 + r) * a.d3 + head * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[qb][c] = *(const u32x4*)(qp + 16 * c + 8 * h);
+  }
+
+  // ---- relative-position tables (log2 domain): row part -> aux[kh][64 queries] (LDS), column part -> 2 x 32 registers
+  float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUXW);
+  f32x16 wreg[2][2];
+  {
+    float* scr = (float*)(smem + wave * AUX_PER_WAVE);  // scratch of the table products: aliases the rings (barrier before staging)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qw = qb * 32 + r;
+#pragma unroll 1
+      for (int tbl = 0; tbl < 2; ++tbl) {
+        const float* table = tbl == 0 ? a.rel_h : a.rel_w;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          f32x16 acc[2];
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
+            const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
+                                                                __builtin_bit_cast(bf16x8, qf[qb][c]), acc[jb], 0, 0, 0);
+          }
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
+          if (tbl == 0) {
+#pragma unroll 4
+            for (int i = 0; i < 32; ++i) {
+              const int kh = 32 * h + i, j = qh + (S - 1) - kh;
+              if ((j >> 6) == half) aux[kh * 64 + qb * 32 + r] = scr[(j & 63) * 32 + r];
+            }
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int kw = kb * 32 + acc_row(e, h), j = qw + (S - 1) - kw;
+                if ((j >> 6) == half) wreg[qb][kb][e] = scr[(j & 63) * 32 + r];
+              }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- staging by LDS-DMA as in flash_global_pipe (same LDS images, same source swizzles); rings of FOUR: K(t) and V(t) live in
+  // slot t & 3. Iteration t reads K(t+1), V(t-1) and issues K(t+3), V(t+2).
+  char* Kring = smem; char* Vring = smem + K_BYTES;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  const unsigned wofs = __builtin_amdgcn_readfirstlane(wave) * 1024u;
+  const int nt = a.Tk / KT;                             // 64 (the launcher requires a 64 x 64 grid)
+  const int srow = tid >> 3, sch = tid & 7;
+  const int kswz = (sch ^ ((srow >> 1) & 7)) * 8;
+  const int vswz = (sch ^ (((srow >> 1) & 1) << 2)) * 8;
+  const unsigned vk0 = (unsigned)((srow * a.d3 + a.H * 64 + kswz) * 2), vk1 = vk0 + (unsigned)(32 * a.d3 * 2);
+  const unsigned vv0 = (unsigned)((srow * a.d3 + 2 * a.H * 64 + vswz) * 2), vv1 = vv0 + (unsigned)(32 * a.d3 * 2);
+  const long tile_bytes = (long)KT * a.d3 * 2;
+  auto issue_k = [&](int t, int slot) {
+    const char* base = (const char*)kvbase + (long)t * tile_bytes;
+    const unsigned d = lds0 + slot * TILE_B + wofs;
+    glds16_so(base, vk0, d);
+    glds16_so(base, vk1, d + 4096);
+  };
+  auto issue_v = [&](int t, int slot) {
+    const char* base = (const char*)kvbase + (long)t * tile_bytes;
+    const unsigned d = lds0 + K_BYTES + slot * TILE_B + wofs;
+    glds16_so(base, vv0, d);
+    glds16_so(base, vv1, d + 4096);
+  };
+  issue_k(0, 0); issue_k(1, 1); issue_k(2, 2); issue_v(0, 0); issue_v(1, 1);
+  *(uint4*)(Vring + 3 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 3)
+  *(uint4*)(Vring + 3 * TILE_B + 4096 + tid * 16) = make_uint4(0, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- fragment read maps (flash_global_pipe's)
+  const int sw = (lane >> 1) & 7;
+  int kch[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kch[c] = r * 128 + (((2 * c + h) ^ sw) << 4);
+  const int v_tr = (4 * h + ((lane & 15) >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int v_trd[2] = {v_tr + ((lane >> 3) & 1) * 64, v_tr + (1 - ((lane >> 3) & 1)) * 64};
+
+  f32x16 o[2][2], s[2][2];
+  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float m[2] = {-INFINITY, -INFINITY};
+  u32x4 pf[2][2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][x][e] = 0.f;
+      pf[qb][x][0] = u32x4{0, 0, 0, 0}; pf[qb][x][1] = u32x4{0, 0, 0, 0};
+    }
+
+  // S(0) (accumulator start value = column bias)
+  {
+    uint4 kf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = *(const uint4*)(Kring + (i >> 2) * 32 * 128 + kch[i & 3]);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        s[qb][kb] = wreg[qb][kb];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[qb][c]), s[qb][kb], 0, 0, 0);
+      }
+  }
+  __syncthreads();                                      // (rings of four: not needed for the K slot, kept as the loop's entry rendezvous)
+
+  // ---- register files. hipcc selects the AGPR form for EVERY builtin MFMA of a 512-register kernel, and the VALU cannot read AGPRs:
+  // scores left in AGPRs cost 64 v_accvgpr_read per tile, and mixed use makes the allocator shuttle O^T between the files around
+  // every branch. So every MFMA of the loop is inline asm with the files spelled out: scores S, their start values (the C operand:
+  // C and D share one file bit) and P in arch VGPRs; O^T, the Q fragments and the K / V fragments (LDS reads straight into AGPRs)
+  // in accumulator registers. What the compiler then no longer does for these instructions (MI355X guide 5.7): hazard padding.
+  // S is read by the VALU only in the NEXT iteration (hundreds of cycles after the last score MFMA); O^T is read by the rescale
+  // (placed behind the whole softmax of the tile) and by the epilogue (behind explicit s_nops).
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("" : "+a"(qf[qb][c]));
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { asm volatile("" : "+v"(s[qb][x])); asm volatile("" : "+v"(wreg[qb][x])); asm volatile("" : "+a"(o[qb][x])); }
+  }
+  const char* ksrc = (const char*)kvbase + 3 * tile_bytes;   // K(t+3) of iteration t (clamped to the last tile: re-read, dropped)
+  const char* vsrc = (const char*)kvbase + 2 * tile_bytes;   // V(t+2)
+  // both copies of a tile in one M0 setting: M0 = destination + 2048, instruction offsets -2048 / +2048 (the offset moves the
+  // LDS address AND the global address, so the per-lane source offsets carry the opposite 2048)
+  const unsigned vk0p = vk0 + 2048u, vk1p = vk1 - 2048u, vv0p = vv0 + 2048u, vv1p = vv1 - 2048u;
+
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    if (!(DBG & 1)) {
+      const unsigned kd = lds0 + (unsigned)((t + 3) & 3) * TILE_B + wofs + 2048u;              // over K(t-1), last read in iteration t-2
+      const unsigned vd = lds0 + K_BYTES + (unsigned)((t + 2) & 3) * TILE_B + wofs + 2048u;    // over V(t-2), last read in iteration t-1
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %3, %5 offset:-2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:2048\n\t"
+                   "s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %6, %8 offset:-2048\n\tglobal_load_lds_dwordx4 %7, %8 offset:2048\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(kd), "s"(vd), "v"(vk0p), "v"(vk1p), "s"(ksrc), "v"(vv0p), "v"(vv1p), "s"(vsrc) : "memory");
+      if (t + 4 < nt) ksrc += tile_bytes;
+      if (t + 3 < nt) vsrc += tile_bytes;
+    }
+    const char *Vs = Vring + ((t + 3) & 3) * TILE_B, *Ks = Kring + ((t + 1) & 3) * TILE_B;   // V(t-1), K(t+1)
+    const float rh0 = aux[t * 64 + r], rh1 = aux[t * 64 + 32 + r];
+    u32x4 vf[8], kf[8];
+    if (DBG & 4) { Vs = Vring; Ks = Kring; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
+      if ((DBG & 4) && t > 0) { vf[i] = u32x4{(unsigned)t, (unsigned)i, 3u, 4u}; continue; }
+      const char* vb = Vs + (kb * 32 + ks * 16) * 128 + v_trd[db];
+      const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+      const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
+      vf[i] = __builtin_bit_cast(u32x4, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((DBG & 4) && t > 0) { kf[i] = u32x4{(unsigned)t, (unsigned)i, 1u, 2u}; continue; }
+      kf[i] = *(const u32x4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // PV(t-1), (qb, kb)-major: P(t-1) of a block is dead once its four MFMAs are issued, before the block's new P is packed
+    auto pv = [&](int n) __attribute__((always_inline)) {
+      const int qb = n >> 3, kb = (n >> 2) & 1, ks = (n >> 1) & 1, db = n & 1;
+      if (DBG & 32) { asm volatile("" : "+a"(o[qb][db]) : "a"(vf[kb * 4 + ks * 2 + db]), "v"(pf[qb][kb][ks])); return; }
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "a"(vf[kb * 4 + ks * 2 + db]), "v"(pf[qb][kb][ks]));
+    };
+    // S(t+1) block g = (qb, kb), k-step c, in place of S(t)'s consumed block
+    auto qk = [&](int g, int c) __attribute__((always_inline)) {
+      const int qb = g >> 1, kb = g & 1;
+      if (DBG & 64) { asm volatile("" : "+v"(s[qb][kb]) : "a"(kf[kb * 4 + c]), "a"(qf[qb][c]), "v"(wreg[qb][kb])); return; }
+      if (c == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[qb][kb]) : "a"(kf[kb * 4 + c]), "a"(qf[qb][c]), "v"(wreg[qb][kb]));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[qb][kb]) : "a"(kf[kb * 4 + c]), "a"(qf[qb][c]));
+    };
+    // ---- part 1: tile maxima of S(t) (the fragment reads above land meanwhile), then the first two PV(t-1) MFMAs beside the rest
+    float mloc[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float m4[4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int e = 8 * g;
+          const f32x16& x = s[qb][kb];
+          if (DBG & 16) { m4[kb * 2 + g] = x[e]; continue; }
+          const float t0 = max3f_(x[e], x[e + 1], x[e + 2]), t1 = max3f_(x[e + 3], x[e + 4], x[e + 5]);
+          m4[kb * 2 + g] = max3f_(max3f_(t0, t1, x[e + 6]), x[e + 7], -INFINITY);
+        }
+      mloc[qb] = fmaxf(max3f_(m4[0], m4[1], m4[2]), m4[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      pv(qb);
+    }
+    float msub[2], al0 = 1.f, al1 = 1.f;
+    bool resc;
+    {
+      const float ml0 = fmaxf(mloc[0], other_half(mloc[0])) + rh0, ml1 = fmaxf(mloc[1], other_half(mloc[1])) + rh1;   // true tile maxima
+      // lazy rescale (see flash_global_pipe). Fourteen of the sixteen PV(t-1) MFMAs, whose P is relative to the OLD reference, are still
+      // to be issued: the row sums (complete up to tile t-1) move to the new reference now, O^T only at the END of the iteration
+      resc = __builtin_amdgcn_ballot_w64(ml0 > m[0] + 8.0f || ml1 > m[1] + 8.0f) != 0;
+      if (resc) {
+        const float mn0 = fmaxf(m[0], ml0), mn1 = fmaxf(m[1], ml1);
+        al0 = __builtin_amdgcn_exp2f(m[0] - mn0); al1 = __builtin_amdgcn_exp2f(m[1] - mn1);
+        m[0] = mn0; m[1] = mn1;
+        lsum[0][0] *= al0; lsum[0][1] *= al0; lsum[1][0] *= al1; lsum[1][1] *= al1;
+      }
+      msub[0] = m[0] - rh0; msub[1] = m[1] - rh1;       // p = 2^(x + rh - m)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- part 2: the softmax of S(t) in 16 steps of four scores (4 sub + 4 exp2, and 2 cvt_pk + 2 dot2 for the previous step's four),
+    // block g = (qb, kb) in steps 4g .. 4g+3; once a block's scores are consumed its registers take S(t+1) IN PLACE (4 MFMAs, start
+    // value = column bias). MFMAs per step: PV 2..9 two per step beside block 0; PV 10..13 + QK block 0 beside block 1; PV 14, 15 +
+    // QK block 1 beside block 2; QK block 2 beside block 3; QK block 3 runs under the wait, the barrier and the next iteration's
+    // copies and reads. One MFMA per half step: sched_barrier pins the order (sched_group_barrier does not see asm as an MFMA).
+    float pe[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c <= 16; ++c) {
+      float pn[4];
+      uint32_t d0 = 0, d1 = 0;
+      const int cp = c - 1, gp = cp >> 2, qbp = gp >> 1, kbp = gp & 1, k4 = cp & 3;
+      if (c < 16) {
+        const int g = c >> 2, qb = g >> 1, kb = g & 1, e0 = 4 * (c & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
+      }
+      if (c > 0) { d0 = pk2(pe[0], pe[1]); lsum[qbp][k4 & 1] = sum2_bf16(d0, lsum[qbp][k4 & 1]); }
+      // first MFMA of the step
+      if (c < 4) pv(2 + 2 * c);
+      else if (c < 8) pv(6 + c);
+      else if (c < 10) pv(6 + c);
+      else if (c < 12) qk(1, c - 8);
+      else if (c < 16) qk(2, c - 12);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c < 16) {
+        const int g = c >> 2, qb = g >> 1, kb = g & 1, e0 = 4 * (c & 3);
+#pragma unroll
+        for (int i = 2; i < 4; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
+      }
+      if (c > 0) {
+        d1 = pk2(pe[2], pe[3]); lsum[qbp][k4 & 1] = sum2_bf16(d1, lsum[qbp][k4 & 1]);
+        u32x4& dst = pf[qbp][kbp][k4 >> 1];
+        if (k4 & 1) { dst[2] = d0; dst[3] = d1; } else { dst[0] = d0; dst[1] = d1; }
+      }
+      // second MFMA of the step
+      if (c < 4) pv(3 + 2 * c);
+      else if (c < 8) qk(0, c - 4);
+      else if (c < 10) qk(1, c - 8);
+      else if (c == 16) { qk(3, 0); qk(3, 1); qk(3, 2); qk(3, 3); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pe[i] = pn[i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (the softmax arithmetic above is pure: without this use LLVM sinks all of it below the branch that follows, away from the MFMAs)
+    asm volatile("" :: "v"(lsum[0][0]), "v"(lsum[0][1]), "v"(lsum[1][0]), "v"(lsum[1][1]));
+    if (resc) {                                          // every PV(t-1) MFMA was issued steps ago, no PV(t) yet: O^T moves to the new reference
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float x0 = o[0][db][e], x1 = o[1][db][e], t0, t1;
+          asm volatile("v_accvgpr_read_b32 %2, %0\n\tv_accvgpr_read_b32 %3, %1\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %5\n\t"
+                       "v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3"
+                       : "+a"(x0), "+a"(x1), "=&v"(t0), "=&v"(t1) : "v"(al0), "v"(al1));
+          o[0][db][e] = x0; o[1][db][e] = x1;
+        }
+    }
+    if (!(DBG & 2)) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K(t+2) (issued one iteration ago) has landed, V(t) long since; the younger six stay in flight
+      __syncthreads();
+    }
+  }
+  // PV(nt-1)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* Vs = Vring + ((nt - 1) & 3) * TILE_B;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* vb = Vs + (kb * 32 + ks * 16) * 128 + v_trd[db];
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * 128));
+          const u32x4 vfr = __builtin_bit_cast(u32x4, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "a"(vfr), "v"(pf[qb][kb][ks]));
+        }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the last MFMA's 16 passes + write-back before O^T is read (no compiler padding behind asm)
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l = lsum[qb][0] + lsum[qb][1];
+    const float inv = 1.0f / (l + other_half(l));       // full row sum: both lane halves
+    auto off = [&](int j) -> long { return ((long)b * g2 + qh * S + qb * 32 + j) * (long)(a.H * 64) + head * 64; };
+    store_o_rows<TO, 64>(o[qb], inv, (char*)aux, (TO*)a.o, lane, off);   // the wave's row-bias table is dead: private staging
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Windowed SAM attention (14x14 windows), ONE block per (window, head): 7 waves x 32 queries (224 slots for the 196 queries,
 // 12.5 % padding; flash_fwd<2> ran two 128-query blocks per (window, head): 23 % padding and every K/V byte staged twice).
 //   * K and V of the whole window (2 x 224 rows x 128 B = 56 KiB) are staged ONCE by LDS-DMA while the waves build their
@@ -1045,6 +1395,18 @@ int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
   return 0;
 }
 
+template <typename TO, int DBG = 0>
+int launch_global_w64(const FlashArgs& a, int nb, hipStream_t s) {
+  const size_t lds = 8 * TILE_B + 4 * 64 * 64 * 4;     // 128 KiB: one block (4 waves x 64 queries) per CU
+  static DevOnce once;
+  cor_max_dyn_lds((const void*)flash_global_w64<TO, DBG>, (int)lds, once);
+  FlashArgs b = a;
+  b.nqt = a.Tq / 256;
+  hipLaunchKernelGGL((flash_global_w64<TO, DBG>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int MODE, typename TO, int HD = 64>
 int launch(const FlashArgs& a, int nb, hipStream_t s) {
   constexpr int ROWB = HD == 64 ? 128 : 208;
@@ -1093,9 +1455,9 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   const int rev = (variant & COR_ORDER_REVERSE) ? 1 : 0;
   variant &= ~COR_ORDER_REVERSE;
 #ifdef COR_PROBES
-  if (variant != 0 && variant != 1 && variant != 9) return COR_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 9 && !(variant >= 16 && variant < 144)) return COR_EINVAL;
 #else
-  if (variant != 0 && variant != 1) return COR_EINVAL;   // no probe / experimental kernels in the production library
+  if (variant != 0 && variant != 1 && variant != 2) return COR_EINVAL;   // no probe / experimental kernels in the production library
 #endif
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
@@ -1108,12 +1470,32 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
 #ifdef COR_PROBES
+    if (variant >= 16 && out_dtype == COR_BF16 && a.scale_log2 == 1.0f) {   // timing ablations of flash_global_w64 (garbage results)
+      switch (variant - 16) {
+        case 1: return launch_global_w64<bf16_t, 1>(a, B, s);
+        case 2: return launch_global_w64<bf16_t, 2>(a, B, s);
+        case 3: return launch_global_w64<bf16_t, 3>(a, B, s);
+        case 4: return launch_global_w64<bf16_t, 4>(a, B, s);
+        case 8: return launch_global_w64<bf16_t, 8>(a, B, s);
+        case 16: return launch_global_w64<bf16_t, 16>(a, B, s);
+        case 32: return launch_global_w64<bf16_t, 32>(a, B, s);
+        case 64: return launch_global_w64<bf16_t, 64>(a, B, s);
+        case 96: return launch_global_w64<bf16_t, 96>(a, B, s);
+        case 7: return launch_global_w64<bf16_t, 7>(a, B, s);
+        case 127: return launch_global_w64<bf16_t, 127>(a, B, s);
+        default: return COR_EINVAL;
+      }
+    }
     if (variant == 9) {
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t, true>(a, B, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float, true>(a, B, s);
     }
 #endif
-    if (variant == 0) {
+    if (variant == 0 && a.scale_log2 == 1.0f) {        // pre-scaled q (the engine's path): 64 queries per wave, bias as the MFMA's C operand
+      if (out_dtype == COR_BF16) return launch_global_w64<bf16_t>(a, B, s);
+      if (out_dtype == COR_F32) return launch_global_w64<float>(a, B, s);
+    }
+    if (variant == 0 || variant == 2) {
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, s);
     }

@@ -452,7 +452,7 @@ def test_production_library_rejects_probe_and_experimental_selectors():
     ops, _ = _ops()
     qkv = torch.zeros((4096, 3 * 64), device=DEV, dtype=BF16)
     rel = torch.zeros((127, 64), device=DEV)
-    for variant in (2, 3, 4, 5, 6, 9, 10, 14, 77):
+    for variant in (3, 4, 5, 6, 9, 10, 14, 77):
         with pytest.raises(nat.NativeError):
             ops.sam_attention(qkv, None, rel, rel, 1, 1, 64, 0, variant=variant)
     a = torch.zeros((256, 128), device=DEV, dtype=BF16)
