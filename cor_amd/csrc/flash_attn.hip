@@ -15,6 +15,7 @@
 //   windowed (S = 14): both parts are looked up per score in two small per-wave LDS tables.
 // Window partition, zero padding (a padded token's q/k/v is the qkv bias row) and un-partition are addressing only.
 // Scores are kept in the log2 domain (scale*log2e folded in) so the exponential is a bare v_exp_f32.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -489,7 +490,9 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 // code is in the history up to commit 5d3e0f7): bias / running reference as extra k-steps of the score MFMA (+1 % / +12 %), 8-wave
 // blocks (+5 %), an explicit ping-pong form with alternating matrix / softmax segments (+5 %), row sums of P by a ones-row MFMA (+4 %).
 // STAMP (COR_PROBES builds only, tools/attn_stamps.py): per-section cycle sums are written INSTEAD of the outputs.
-template <typename TO, bool STAMP = false>
+// CB (round 5): q arrives pre-scaled (scale_log2 == 1), so the column bias is the C OPERAND of the first score MFMA of each chain
+// (accumulator start value) instead of one fma per score: 32 vector instructions fewer per tile and wave.
+template <typename TO, bool STAMP = false, bool CB = false>
 __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {   // 4 waves x 32 queries per block
   constexpr int NW = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -514,49 +517,45 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) qf[c] = *(const uint4*)(qp + 16 * c + 8 * h);
 
-  // ---- relative-position tables (log2 domain): row part -> aux[kh][q] (LDS), column part -> 32 registers
+  // ---- relative-position tables (log2 domain): row part -> aux[kh][q] (LDS), column part -> 32 registers.
+  // Round 5 (the fixed part of a block was 16 % of the kernel: four sequential rounds of table loads -> MFMA -> LDS -> 32 conditional
+  // copies): the 32 queries of a wave share ONE grid row qh (32 | 64), so
+  //   * row part: the A operand's rows are the table rows in the order the tiles need them, row i <- table row qh + 63 - i (i = kh):
+  //     the accumulator IS Th[kh][q] in score layout and goes to aux directly (8 MFMAs, 32 LDS writes, no scratch);
+  //   * column part: a lane needs table rows j = qw + 63 - kw, qw = 32 pw + r: local rows r + 63 - kw in [0, 94] of the 96-row window
+  //     that starts at 32 pw -> 12 MFMAs, 48 LDS writes, 32 conflict-free LDS reads along the lane's diagonal (no conditions);
+  //   * every table fragment load is issued before the first MFMA (straight-line code): one load latency instead of four.
   float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUX_PER_WAVE);
-  float wreg[2][16];
+  f32x16 wreg[2];
+  uint4 fh[2][4];
   {
-    // scratch of the table products: aliases the K/V rings (barrier before staging)
-    float* scr = (float*)(smem + wave * AUX_PER_WAVE);
-#pragma unroll 1
-    for (int tbl = 0; tbl < 2; ++tbl) {
-      const float* table = tbl == 0 ? a.rel_h : a.rel_w;
-#pragma unroll 1
-      for (int half = 0; half < 2; ++half) {
-        f32x16 acc[2];
+    float* scr = (float*)(smem + wave * (3 * 4096));    // 96 rows x 32 queries x 4 B: aliases the K/V rings (barrier before staging)
+    const int pw = (qt_ * NW + wave) & 1;               // which half of the grid row the wave's queries are (qw = 32 pw + r)
+    uint4 fw[3][4];
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
-          const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
+      for (int c = 0; c < 4; ++c) fh[kb][c] = table_frag(a.rel_h, qh + (S - 1) - (kb * 32 + r), c, h);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
-                                                              __builtin_bit_cast(bf16x8, qf[c]), acc[jb], 0, 0, 0);
-        }
+    for (int jb = 0; jb < 3; ++jb)
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
+      for (int c = 0; c < 4; ++c) fw[jb][c] = table_frag(a.rel_w, min(32 * pw + jb * 32 + r, 2 * S - 2), c, h);
 #pragma unroll
-          for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
-        if (tbl == 0) {
-#pragma unroll 4
-          for (int i = 0; i < 32; ++i) {
-            const int kh = 32 * h + i, j = qh + (S - 1) - kh;
-            if ((j >> 6) == half) aux[kh * 32 + r] = scr[(j & 63) * 32 + r];
-          }
-        } else {
+    for (int jb = 0; jb < 3; ++jb) {
+      f32x16 acc;
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int kw = kb * 32 + acc_row(e, h), j = qw + (S - 1) - kw;
-              if ((j >> 6) == half) wreg[kb][e] = scr[(j & 63) * 32 + r];
-            }
-        }
-      }
+      for (int c = 0; c < 4; ++c)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[jb][c]), __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[e] * a.tbl_scale;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // lanes exchange data through LDS (compiler-only fence)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) wreg[kb][e] = scr[(r + (S - 1) - (kb * 32 + acc_row(e, h))) * 32 + r];
   }
   __syncthreads();
 
@@ -591,9 +590,27 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     glds16_so(base, vv0, d);
     glds16_so(base, vv1, d + 4096);
   };
+  // (the converted row-table fragments are pinned BEFORE the copies: hipcc waits for its own loads with vmcnt(0) when it cannot
+  // count the asm copies behind them, which would drain the copies too)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(fh[kb][c].x), "+v"(fh[kb][c].y), "+v"(fh[kb][c].z), "+v"(fh[kb][c].w));
   issue_k(0, 0); issue_k(1, 1); issue_k(2, 2); issue_v(0, 0);
   *(uint4*)(Vring + 2 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);          // V tile "-1" (slot 2)
   *(uint4*)(Vring + 2 * TILE_B + 4096 + tid * 16) = make_uint4(0, 0, 0, 0);
+  // the row part of the bias while the first tiles are in flight (it needs no scratch: accumulator layout = aux layout)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh[kb][c]), __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) aux[(kb * 32 + acc_row(e, h)) * 32 + r] = acc[e] * a.tbl_scale;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -621,7 +638,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+    for (int e = 0; e < 16; ++e) s[kb][e] = CB ? wreg[kb][e] : 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint4 kf = *(const uint4*)(Kring + kb * 32 * 128 + kch[c]);
@@ -668,7 +685,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[kb][e] = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]);
+        for (int e = 0; e < 16; ++e) if (!CB) s[kb][e] = fmaf(s[kb][e], a.scale_log2, wreg[kb][e]);
       // tile maximum of the lane's 32 scores as a tree of v_max3_f32: 16 instructions (a running max3 chain came out as 17 v_max + 8 v_max3)
       float m4[4];
 #pragma unroll
@@ -681,9 +698,9 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
         }
       mloc = fmaxf(max3f_(m4[0], m4[1], m4[2]), m4[3]);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU
+      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU (CB: 2)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, CB ? 2 : 4, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -711,7 +728,7 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
+      for (int e = 0; e < 16; ++e) sn[kb][e] = CB ? wreg[kb][e] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -832,51 +849,53 @@ __global__ void __launch_bounds__(256, 1) flash_global_w64(const FlashArgs a) { 
     for (int c = 0; c < 4; ++c) qf[qb][c] = *(const u32x4*)(qp + 16 * c + 8 * h);
   }
 
-  // ---- relative-position tables (log2 domain): row part -> aux[kh][64 queries] (LDS), column part -> 2 x 32 registers
+  // ---- relative-position tables (log2 domain): row part -> aux[kh][64 queries] (LDS), column part -> 2 x 32 registers.
+  // As in flash_global_pipe (round 5): the row part's A operand holds table rows qh + 63 - i, so the accumulator is Th[kh][q] in score
+  // layout (straight to aux); the column part of q-block qb needs the 96-row window that starts at table row 32 qb; the row-table
+  // fragments serve both q-blocks, the column table's four 32-row blocks too (blocks qb .. qb + 2); all loads before the first MFMA.
   float* aux = (float*)(smem + K_BYTES + V_BYTES + wave * AUXW);
   f32x16 wreg[2][2];
   {
-    float* scr = (float*)(smem + wave * AUX_PER_WAVE);  // scratch of the table products: aliases the rings (barrier before staging)
+    float* scr = (float*)(smem + wave * (3 * 4096));    // 96 rows x 32 queries x 4 B: aliases the rings (barrier before staging)
+    uint4 fh[2][4], fw[4][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fh[kb][c] = table_frag(a.rel_h, qh + (S - 1) - (kb * 32 + r), c, h);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fw[jb][c] = table_frag(a.rel_w, min(jb * 32 + r, 2 * S - 2), c, h);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      const int qw = qb * 32 + r;
-#pragma unroll 1
-      for (int tbl = 0; tbl < 2; ++tbl) {
-        const float* table = tbl == 0 ? a.rel_h : a.rel_w;
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-          f32x16 acc[2];
 #pragma unroll
-          for (int jb = 0; jb < 2; ++jb) {
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[jb][e] = 0.f;
-            const int j = min(64 * half + jb * 32 + r, 2 * S - 2);
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-              acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)),
-                                                                __builtin_bit_cast(bf16x8, qf[qb][c]), acc[jb], 0, 0, 0);
-          }
+        for (int c = 0; c < 4; ++c)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh[kb][c]), __builtin_bit_cast(bf16x8, qf[qb][c]), acc, 0, 0, 0);
 #pragma unroll
-          for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[jb][e] * a.tbl_scale;
-          if (tbl == 0) {
-#pragma unroll 4
-            for (int i = 0; i < 32; ++i) {
-              const int kh = 32 * h + i, j = qh + (S - 1) - kh;
-              if ((j >> 6) == half) aux[kh * 64 + qb * 32 + r] = scr[(j & 63) * 32 + r];
-            }
-          } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int kw = kb * 32 + acc_row(e, h), j = qw + (S - 1) - kw;
-                if ((j >> 6) == half) wreg[qb][kb][e] = scr[(j & 63) * 32 + r];
-              }
-          }
-        }
+        for (int e = 0; e < 16; ++e) aux[(kb * 32 + acc_row(e, h)) * 64 + qb * 32 + r] = acc[e] * a.tbl_scale;
       }
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[qb + jb][c]), __builtin_bit_cast(bf16x8, qf[qb][c]), acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) scr[(jb * 32 + acc_row(e, h)) * 32 + r] = acc[e] * a.tbl_scale;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // lanes exchange data through LDS (compiler-only fence)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wreg[qb][kb][e] = scr[(r + (S - 1) - (kb * 32 + acc_row(e, h))) * 32 + r];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // the second q-block reuses the scratch
     }
   }
   __syncthreads();
@@ -1065,9 +1084,9 @@ __global__ void __launch_bounds__(256, 1) flash_global_w64(const FlashArgs a) { 
       if (c < 16) {
         const int g = c >> 2, qb = g >> 1, kb = g & 1, e0 = 4 * (c & 3);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
+        for (int i = 0; i < 2; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : (DBG & 256) ? __builtin_amdgcn_exp2f(s[qb][kb][e0 + i]) : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
       }
-      if (c > 0) { d0 = pk2(pe[0], pe[1]); lsum[qbp][k4 & 1] = sum2_bf16(d0, lsum[qbp][k4 & 1]); }
+      if (c > 0) { d0 = pk2(pe[0], pe[1]); if (!(DBG & 128)) lsum[qbp][k4 & 1] = sum2_bf16(d0, lsum[qbp][k4 & 1]); else if (c == 1) lsum[qbp][k4 & 1] += __uint_as_float(d0); }
       // first MFMA of the step
       if (c < 4) pv(2 + 2 * c);
       else if (c < 8) pv(6 + c);
@@ -1078,10 +1097,10 @@ __global__ void __launch_bounds__(256, 1) flash_global_w64(const FlashArgs a) { 
       if (c < 16) {
         const int g = c >> 2, qb = g >> 1, kb = g & 1, e0 = 4 * (c & 3);
 #pragma unroll
-        for (int i = 2; i < 4; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
+        for (int i = 2; i < 4; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : (DBG & 256) ? __builtin_amdgcn_exp2f(s[qb][kb][e0 + i]) : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
       }
       if (c > 0) {
-        d1 = pk2(pe[2], pe[3]); lsum[qbp][k4 & 1] = sum2_bf16(d1, lsum[qbp][k4 & 1]);
+        d1 = pk2(pe[2], pe[3]); if (!(DBG & 128)) lsum[qbp][k4 & 1] = sum2_bf16(d1, lsum[qbp][k4 & 1]);
         u32x4& dst = pf[qbp][kbp][k4 >> 1];
         if (k4 & 1) { dst[2] = d0; dst[3] = d1; } else { dst[0] = d0; dst[1] = d1; }
       }
@@ -1383,14 +1402,14 @@ int launch_win(const FlashArgs& a, int nwin, hipStream_t s) {
   return 0;
 }
 
-template <typename TO, bool STAMP = false>
+template <typename TO, bool STAMP = false, bool CB = false>
 int launch_global_pipe(const FlashArgs& a, int nb, hipStream_t s) {
   const size_t lds = 6 * TILE_B + 4 * AUX_PER_WAVE;    // 80 KiB: two blocks per CU
   static DevOnce once;
-  cor_max_dyn_lds((const void*)flash_global_pipe<TO, STAMP>, (int)lds, once);
+  cor_max_dyn_lds((const void*)flash_global_pipe<TO, STAMP, CB>, (int)lds, once);
   FlashArgs b = a;
   b.nqt = cdiv(a.Tq, 128);
-  hipLaunchKernelGGL((flash_global_pipe<TO, STAMP>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((flash_global_pipe<TO, STAMP, CB>), dim3(b.nqt * a.H * nb), dim3(256), lds, s, b);
   COR_CHECK_LAUNCH();
   return 0;
 }
@@ -1428,9 +1447,11 @@ int launch_t(const FlashArgs& a, int nb, int out_dtype, hipStream_t s) {
 
 }  // namespace
 
-// `variant` (per call): 0 (default) = flash_global_pipe (global; software-pipelined over key tiles) / win_attn (windowed; one
-// 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>, the round-1 chain forms of the same arithmetic, kept as the
-// in-process A/B and parity partners (tests/test_gpu_parity.py, tools/attn_bench.py). Anything else is COR_EINVAL in the
+// `variant` (per call): 0 (default) = flash_global_pipe (global; software-pipelined over key tiles; with a pre-scaled q the column
+// bias is the score MFMA's C operand) / win_attn (windowed; one 7-wave block per (window, head)); 1 = flash_fwd<1> / flash_fwd<2>,
+// the round-1 chain forms of the same arithmetic, kept as the in-process A/B and parity partners (tests/test_gpu_parity.py,
+// tools/attn_bench.py); 2 = flash_global_pipe with the bias as one fma per score (round 4's default; A/B partner); 4 =
+// flash_global_w64 (64 queries per wave, one wave per SIMD: built in round 5, parity-green, slower - DESIGN 3.2). Anything else is COR_EINVAL in the
 // production library; a COR_PROBES build (make probes -> tools/probes/libcor_probes.so) adds 9 = the timing probe of the default
 // global kernel (per-wave s_memtime sums per loop section INSTEAD of the outputs: tools/attn_stamps.py).
 int cor_flash_plain_bf16(const void* q, long q_sb, long q_st, const void* k, long k_sb, long k_st, const void* v, long v_sb, long v_st,
@@ -1455,9 +1476,9 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   const int rev = (variant & COR_ORDER_REVERSE) ? 1 : 0;
   variant &= ~COR_ORDER_REVERSE;
 #ifdef COR_PROBES
-  if (variant != 0 && variant != 1 && variant != 2 && variant != 9 && !(variant >= 16 && variant < 144)) return COR_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 9 && !(variant >= 16 && variant < 1024)) return COR_EINVAL;
 #else
-  if (variant != 0 && variant != 1 && variant != 2) return COR_EINVAL;   // no probe / experimental kernels in the production library
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4) return COR_EINVAL;   // no probe / experimental kernels in the production library
 #endif
   if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15)) return COR_ENOSUPPORT;
   FlashArgs a{};
@@ -1468,6 +1489,9 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   if (window == 0) {
     if (grid != 64) return COR_ENOSUPPORT;            // one key row per 64-key tile
     a.S = 64; a.Tq = a.Tk = grid * grid; a.nW = 1;
+#ifdef COR_PROBES
+    if (const char* e = getenv("COR_ATTN_TK")) a.Tk = atoi(e);   // timing probe: fewer key tiles (garbage results): prologue + epilogue share
+#endif
     if (hd == 80) return launch_t<1, 80>(a, B, out_dtype, s);     // SAM-H: the chain form (the pipelined kernel is head_dim 64 only)
 #ifdef COR_PROBES
     if (variant >= 16 && out_dtype == COR_BF16 && a.scale_log2 == 1.0f) {   // timing ablations of flash_global_w64 (garbage results)
@@ -1483,6 +1507,9 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
         case 96: return launch_global_w64<bf16_t, 96>(a, B, s);
         case 7: return launch_global_w64<bf16_t, 7>(a, B, s);
         case 127: return launch_global_w64<bf16_t, 127>(a, B, s);
+        case 128: return launch_global_w64<bf16_t, 128>(a, B, s);
+        case 256: return launch_global_w64<bf16_t, 256>(a, B, s);
+        case 384: return launch_global_w64<bf16_t, 384>(a, B, s);
         default: return COR_EINVAL;
       }
     }
@@ -1491,11 +1518,15 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
       if (out_dtype == COR_F32) return launch_global_pipe<float, true>(a, B, s);
     }
 #endif
-    if (variant == 0 && a.scale_log2 == 1.0f) {        // pre-scaled q (the engine's path): 64 queries per wave, bias as the MFMA's C operand
+    if (variant == 4 && a.scale_log2 == 1.0f) {        // experimental: 64 queries per wave at one wave per SIMD (measured slower)
       if (out_dtype == COR_BF16) return launch_global_w64<bf16_t>(a, B, s);
       if (out_dtype == COR_F32) return launch_global_w64<float>(a, B, s);
     }
-    if (variant == 0 || variant == 2) {
+    if (variant == 0 && a.scale_log2 == 1.0f) {        // pre-scaled q (the engine's path): column bias as the score MFMA's C operand
+      if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t, false, true>(a, B, s);
+      if (out_dtype == COR_F32) return launch_global_pipe<float, false, true>(a, B, s);
+    }
+    if (variant == 0 || variant == 2 || variant == 4) {
       if (out_dtype == COR_BF16) return launch_global_pipe<bf16_t>(a, B, s);
       if (out_dtype == COR_F32) return launch_global_pipe<float>(a, B, s);
     }

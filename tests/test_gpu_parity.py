@@ -421,6 +421,11 @@ def test_global_attention_pipelined_vs_fp64_reference_and_chain_kernel(B, H, amp
     o_p = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c)             # what the engine runs
     assert torch.equal(o_p, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c))
     o_c = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=1)
+    # round 5: with a pre-scaled q the default folds the column bias into the score MFMA's accumulator start value; variant 2 = the
+    # fma form (round 4's default), variant 4 = flash_global_w64 (64 queries per wave, one wave per SIMD, asm MFMAs, deferred rescale)
+    o_f = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=2)
+    o_w = ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=4)
+    assert torch.equal(o_w, ops.sam_attention(qs, ps, rh, rw, B, H, 64, 0, out_dtype=F32, q_prescale=c, variant=4))
     hard = amp > 2
     # (a) fp64 reference on sampled (image, head) pairs
     x = qkv.view(B, 4096, 3, H, 64)
@@ -433,7 +438,9 @@ def test_global_attention_pipelined_vs_fp64_reference_and_chain_kernel(B, H, amp
         ref = torch.softmax((q * 0.125) @ k.T + bias, dim=-1) @ v
         scale = float(ref.abs().max())
         for name, got, tol, rl in (("pipe", out, 2e-2, 4e-3), ("chain", chain, 2e-2, 4e-3), ("pipe_prescaled", o_p, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3),
-                                   ("chain_prescaled", o_c, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3)):
+                                   ("chain_prescaled", o_c, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3),
+                                   ("pipe_fma_prescaled", o_f, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3),
+                                   ("w64_prescaled", o_w, 8e-2 if hard else 2e-2, 1.5e-2 if hard else 5e-3)):
             r = report(f"global_attn_{name}_vs_fp64_B{B}_H{H}_amp{amp}_b{b}_h{hh}", got.view(B, 4096, H, 64)[b, :, hh], ref.float(), rtol=0, atol=tol * scale)
             assert r["rel_l2"] <= rl * max(1.0, amp if not hard else 1.0), (name, b, hh, r)
             worst[name] = max(worst.get(name, 0.0), r["rel_l2"])
@@ -443,6 +450,9 @@ def test_global_attention_pipelined_vs_fp64_reference_and_chain_kernel(B, H, amp
     tol = 8e-2 if hard else 2e-2
     r_p = report(f"global_attn_prescaled_vs_chain_B{B}_H{H}_amp{amp}", o_p, chain, rtol=tol, atol=tol * float(chain.abs().max()))
     assert r_p["rel_l2"] <= (2e-2 if hard else 5e-3), r_p
+    for name, got in (("fma", o_f), ("w64", o_w)):
+        r_v = report(f"global_attn_prescaled_{name}_vs_chain_B{B}_H{H}_amp{amp}", got, chain, rtol=tol, atol=tol * float(chain.abs().max()))
+        assert r_v["rel_l2"] <= (2e-2 if hard else 5e-3), r_v
 
 
 def test_production_library_rejects_probe_and_experimental_selectors():
@@ -452,7 +462,7 @@ def test_production_library_rejects_probe_and_experimental_selectors():
     ops, _ = _ops()
     qkv = torch.zeros((4096, 3 * 64), device=DEV, dtype=BF16)
     rel = torch.zeros((127, 64), device=DEV)
-    for variant in (3, 4, 5, 6, 9, 10, 14, 77):
+    for variant in (3, 5, 6, 9, 10, 14, 16, 17, 77):
         with pytest.raises(nat.NativeError):
             ops.sam_attention(qkv, None, rel, rel, 1, 1, 64, 0, variant=variant)
     a = torch.zeros((256, 128), device=DEV, dtype=BF16)
@@ -1747,6 +1757,12 @@ def test_reverse_work_order_is_bit_identical():
         for variant in (0, 1):
             assert torch.equal(ops.sam_attention(qkv, pad, rh, rw, B, H, 64, win, variant=variant),
                                ops.sam_attention(qkv, pad, rh, rw, B, H, 64, win, variant=variant, reverse=True)), (win, variant)
+        if win == 0:                                      # the pre-scaled forms of the global kernel (what the engine runs; the 64-query-per-wave form)
+            from cor_amd import _native as nat
+            c = nat.Q_PRESCALE_HD64
+            for variant in (0, 4):
+                assert torch.equal(ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, variant=variant, q_prescale=c),
+                                   ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, variant=variant, q_prescale=c, reverse=True)), variant
 
 
 @pytest.mark.parametrize("mode", [F32, BF16])

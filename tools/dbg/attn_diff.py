@@ -13,8 +13,8 @@ qkv = torch.randn((B * 4096, 3 * d), device=dev).to(torch.bfloat16)
 pad = torch.randn((3 * d,), device=dev).to(torch.bfloat16)
 rh = torch.randn((127, 64), device=dev) * 0.3
 rw = torch.randn((127, 64), device=dev) * 0.3
-a = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=torch.float32, q_prescale=QC, variant=0).view(4096, H, 64)
-b = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=torch.float32, q_prescale=QC, variant=2).view(4096, H, 64)
+a = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=torch.float32, q_prescale=QC, variant=int(sys.argv[1]) if len(sys.argv) > 1 else 0).view(4096, H, 64)
+b = ops.sam_attention(qkv, pad, rh, rw, B, H, 64, 0, out_dtype=torch.float32, q_prescale=QC, variant=int(sys.argv[2]) if len(sys.argv) > 2 else 2).view(4096, H, 64)
 err = (a - b).abs()
 bad = err > 0.05
 print("bad elements", int(bad.sum()), "of", bad.numel(), "max", float(err.max()))
