@@ -1235,16 +1235,19 @@ __global__ void __launch_bounds__(448, 4) win_attn(const FlashArgs a) {
   // ---- 3. rel-pos tables from the UNSCALED q, log2 domain: T[j][q] = log2e * Rtable[j,:] . q. Column table first (gathered
   // into 8 registers), then the row table, which stays in the wave's LDS region for the main loop.
   float colb[8];
-#pragma unroll 1
+  uint4 tf[2][4];                                       // both tables' fragments are loaded before the first product (one load latency, not two)
+#pragma unroll
+  for (int tbl = 0; tbl < 2; ++tbl)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tf[tbl][c] = table_frag(tbl == 0 ? a.rel_w : a.rel_h, min(r, 26), c, h);
+#pragma unroll
   for (int tbl = 0; tbl < 2; ++tbl) {
-    const float* table = tbl == 0 ? a.rel_w : a.rel_h;
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int j = min(r, 26);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, table_frag(table, j, c, h)), __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tf[tbl][c]), __builtin_bit_cast(bf16x8, qf[c]), acc, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = acc_row(e, h);

@@ -11,7 +11,7 @@ d = H * 64
 qkv = torch.randn((B * g * g, 3 * d), device=dev).to(T)
 pad = torch.randn((3 * d,), device=dev).to(T)
 from cor_amd._native import Q_PRESCALE_HD64 as QC
-for window, S, variant, qp in ((0, 64, 0, QC), (0, 64, 2, QC), (0, 64, 3, QC), (0, 64, 1, 1.0), (0, 64, 0, QC), (0, 64, 2, QC), (0, 64, 3, QC), (0, 64, 1, QC), (14, 14, 0, QC), (14, 14, 1, 1.0), (14, 14, 0, QC)):   # variant / q_prescale: per-call choices
+for window, S, variant, qp in ((0, 64, 0, QC), (0, 64, 2, QC), (0, 64, 4, QC), (0, 64, 1, 1.0), (0, 64, 0, QC), (0, 64, 2, QC), (0, 64, 4, QC), (0, 64, 1, QC), (14, 14, 0, QC), (14, 14, 1, 1.0), (14, 14, 0, QC)):   # variant / q_prescale: per-call choices
     rh = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     rw = torch.randn((2 * S - 1, 64), device=dev) * 0.5
     qk = qkv
