@@ -50,6 +50,14 @@ def parse(argv=None):
     ap.add_argument("--sam", default="sam_base")
     ap.add_argument("--siglip", default="ViT-B-16-SigLIP-384")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--gallery-dtype", default=None, choices=["bf16", "fp16", "f32"], help="storage type of the gallery rows (default: bf16 with --dtype bf16, f32 with --dtype f32)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[N] as a preset (model, batch, gallery rows, gallery type; "
+                    "explicit flags given after it still win): 1 = SigLIP-B/16 + SAM-B, batch 32, 10k gallery; 2 = the same with a 100k gallery sharded over --gpus ranks; "
+                    "3 = SigLIP-L/16-384 + SAM-L, batch 64; 4 = the same with a 1M-row fp16 gallery sharded over --gpus ranks. 0 (default): configs[1]'s model and batch with "
+                    "the metric's 100k-row gallery (the headline line)")
+    ap.add_argument("--stagger", type=int, default=1, help="with --inflight > 1: 1 (default) orders a slot's [encoder || support branch] graph behind the previous slot's by an "
+                    "event (ForwardPipeline(stagger=True)); 0: one graph per slot, staggered only by the runtime's stream -> hardware-queue mapping (round 4)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="set GPU_MAX_HW_QUEUES before HIP initialises (0: leave the environment / runtime default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1, 2], help="2: as 1, with the two SigLIP towers as two chains on two streams (round 4); 1: support branch (SigLIP towers, adapter, fusion) beside the SAM encoder: a parallel branch of "
                     "the captured graph / a second HIP stream in eager mode (+3-4 %% end to end). -1 (default): on under --graph 1, off in eager mode, "
@@ -75,7 +83,35 @@ def parse(argv=None):
                     "path one GPU can execute (tests); the line still says n_gpus 1")
     ap.add_argument("--launch-check", action="store_true", help="rehearse the launch path only: every rank joins the process group (gloo: no GPU "
                     "needed), all-reduces its rank and rank 0 prints one JSON line; nothing is benchmarked (tests/test_cpu_host.py)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    given = {a.split("=")[0] for a in (argv if argv is not None else sys.argv[1:]) if a.startswith("--")}
+    if args.config:
+        args.config_text = BASELINE_CONFIGS[args.config]
+        for flag, attr, val in PRESETS[args.config]:
+            if flag not in given:
+                setattr(args, attr, val)
+    else:
+        args.config_text = None
+    if args.gallery_dtype is None:
+        args.gallery_dtype = "bf16" if args.dtype == "bf16" else "f32"
+    return args
+
+
+# BASELINE.json `configs`, verbatim, and what each means for this bench (the sharded ones shard over --gpus ranks)
+BASELINE_CONFIGS = {
+    1: "SigLIP-B/16 + SAM-ViT-B, batch 32, 10k gallery, 1\u00d7MI355X bf16",
+    2: "SigLIP-B/16 + SAM-ViT-B, 100k gallery sharded 8 ways, RCCL all-gather over xGMI",
+    3: "SigLIP-L/14 + SAM-ViT-L, 512\u00d7512 inputs, batch 64, 1\u00d7MI355X (HBM-bound attention tiles)",
+    4: "SigLIP-L/14 + SAM-ViT-L, 1M-region gallery, fp16 embeddings, 8\u00d7MI355X with top-k merge",
+}
+_B = [("--sam", "sam", "sam_base"), ("--siglip", "siglip", "ViT-B-16-SigLIP-384"), ("--batch", "batch", 32)]
+_L = [("--sam", "sam", "sam_large"), ("--siglip", "siglip", "ViT-L-16-SigLIP-384"), ("--batch", "batch", 64)]   # (the factory knows no L/14 tower: L/16-384 is its ViT-L)
+PRESETS = {
+    1: _B + [("--gallery", "gallery", 10000), ("--gallery-dtype", "gallery_dtype", "bf16")],
+    2: _B + [("--gallery", "gallery", 100000), ("--gallery-dtype", "gallery_dtype", "bf16")],
+    3: _L + [("--gallery", "gallery", 100000), ("--gallery-dtype", "gallery_dtype", "bf16")],
+    4: _L + [("--gallery", "gallery", 1000000), ("--gallery-dtype", "gallery_dtype", "fp16")],
+}
 
 
 def launch_plan(gpus: int, env) -> tuple:
@@ -151,7 +187,7 @@ def launch_check(args):
 
 
 NB_CPU = 3          # bounded CPU sample: 3 triplets ~ 14 s on 16 cores (the contract asks for 10-30 s)
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # written by tools/pmc_traffic.py for THIS build
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")   # written by tools/pmc_traffic.py for THIS build
 
 
 def gemm_source_id():
@@ -179,7 +215,8 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
     torch.set_num_threads(ncores)
     sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
     inp = {k: v[:NB_CPU].cpu() for k, v in batch.items()}
-    G32 = gallery_rows_cpu.to(torch.bfloat16).float()   # the stored (bf16) rows, as the oracle sees them
+    gdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[args.gallery_dtype]
+    G32 = gallery_rows_cpu.to(gdt).float()              # the stored rows, as the oracle sees them
     t0 = time.perf_counter()
     with torch.no_grad():
         _, _, feat = omodel.forward(sd, args.sam, args.siglip, "MaskAdapterPooling", inp["query_image_inputs"], inp["support_image_inputs"],
@@ -206,7 +243,7 @@ def cpu_baseline_and_recall(args, model, batch, gallery_rows_cpu, dev, feat_fast
     assert int(where.max()) < Gn and where.unique().numel() == B
     G = gallery_rows_cpu.clone()
     G[where] = torch.nn.functional.normalize(q_ref + 0.1 * torch.randn(q_ref.shape, generator=gen), dim=-1)
-    G = G.to(torch.bfloat16)
+    G = G.to(gdt)
     rs, ri = oret.similarity_topk(q_ref, G.float(), args.topk)                       # fp32 reference features, fp32 CPU product
     _, ri_cpu = oret.similarity_topk(q_cpu, G.float(), args.topk)                    # fp32 CPU oracle end to end (first NB_CPU queries)
     gshard = retrieval.GalleryShard(G.to(dev), 0)
@@ -262,7 +299,10 @@ def main():
     # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). With two forwards in flight the slots' streams and their
     # graph branches SHARE queues, which staggers the two forwards (one's encoder beside the other's tail); with 8 or 16 queues they run in
     # lockstep and a step takes 46.3 instead of 42.6 ms (profiles/r04_pipeline_ab.jsonl, ab10): the measured configuration is pinned.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+    # Round 5: the stagger is explicit (--stagger 1: an event orders consecutive slots' encoder graphs), so the queue count is no longer
+    # pinned: --hw-queues N sets it for A/B runs, otherwise the environment / the runtime's default stands.
+    if args.hw_queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -296,7 +336,8 @@ def main():
     lo, hi = retrieval.shard_bounds(Gtot, world, rank)
     gen = torch.Generator(device="cpu").manual_seed(1234)
     rows_all = torch.nn.functional.normalize(torch.randn((Gtot, 256), generator=gen), dim=-1)
-    shard = retrieval.GalleryShard(rows_all[lo:hi].to(dev), offset=lo, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    gdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[args.gallery_dtype]
+    shard = retrieval.GalleryShard(rows_all[lo:hi].to(dev), offset=lo, dtype=gdt)
 
     host_batch = {k: v.cpu().pin_memory() for k, v in batch.items()} if args.host_inputs else None
     h2d = utils.DoubleBufferedH2D(batch, dev) if args.host_inputs else None     # copy of batch i+1 under the forward of batch i
@@ -309,7 +350,7 @@ def main():
     if args.graph:
         try:
             if args.inflight > 1 and not args.host_inputs:
-                pipe = model.capture_pipeline(**batch, multimask_output=mm, depth=args.inflight, overlap_branches=overlap)
+                pipe = model.capture_pipeline(**batch, multimask_output=mm, depth=args.inflight, overlap_branches=overlap, stagger=bool(args.stagger))
                 graphed = pipe.slots[0][0]
             else:
                 graphed = model.capture(**batch, multimask_output=mm, overlap_branches=overlap)
@@ -318,7 +359,8 @@ def main():
             launch_mode = "hipGraph replay of the forward (model.capture" + (", support branch as a parallel graph branch" if overlap else "") + "); similarity search eager"
             if pipe is not None:
                 launch_mode += (f"; {args.inflight} forwards in flight (model.capture_pipeline: step i replays captured graph i % {args.inflight}, which has its own "
-                                f"buffers, on stream i % {args.inflight}, followed there by its search and the lists' copy to the host)")
+                                f"buffers, on stream i % {args.inflight}, followed there by its search and the lists' copy to the host"
+                                + ("; the slots' [encoder || support branch] graphs are chained by an event, the decoder graph of step i runs beside step i + 1's encoder)" if pipe.stagger else ")"))
         except Exception as e:                           # noqa: BLE001 - the bench must still produce its line
             graphed, pipe = None, None
             launch_mode = f"eager ctypes launches (graph capture failed: {type(e).__name__}: {e})"
@@ -405,14 +447,21 @@ def main():
     n_launch = sum(1 for p in prof if p[3] == T)
     # HBM traffic of that kernel cannot be read live: it comes from the committed rocprofv3 --pmc passes of THIS command
     # (tools/pmc_traffic.py -> profiles/*pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction), per launch.
-    traffic, traffic_note = None, "no PMC pass for this build"
+    traffic, traffic_note, traffic_ratio = None, "no PMC pass for this build", None
+    lps = n_launch // max(args.steps, 1)
     if os.path.exists(PMC_TRAFFIC_FILE) and args.dtype == "bf16" and world == 1 and B == 32 and args.sam == "sam_base":
         try:
             tj = json.load(open(PMC_TRAFFIC_FILE))
-            if tj.get("gemm_source_id") == gemm_source_id():
-                traffic, traffic_note = tj["bytes_per_launch"], f"{os.path.relpath(PMC_TRAFFIC_FILE, ROOT)} (same GEMM sources: {tj['gemm_source_id']})"
+            rel = os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
+            if tj.get("gemm_source_id") != gemm_source_id():
+                traffic_note = f"{rel} was measured on other GEMM sources ({tj.get('gemm_source_id')}): not quoted"
+            elif tj.get("launches_per_step") != lps:
+                # same denominators or nothing (a 215-launch PMC pass was quoted beside a 200-launch step)
+                traffic_note = f"{rel} counts {tj.get('launches_per_step')} GEMM launches per step, this run has {lps}: not quoted"
             else:
-                traffic_note = f"{os.path.relpath(PMC_TRAFFIC_FILE, ROOT)} was measured on other GEMM sources ({tj.get('gemm_source_id')}): not quoted"
+                traffic = tj["bytes_per_step"] / lps
+                traffic_ratio = tj["bytes_per_step"] / (gemm_bytes / max(args.steps, 1))
+                traffic_note = f"{rel} (same GEMM sources {tj['gemm_source_id']}, same {lps} launches per step; bytes per step {tj['bytes_per_step']:.4g})"
         except Exception as e:                           # noqa: BLE001
             traffic_note = f"unreadable PMC file: {e}"
     peak = 2500.0 if T == torch.bfloat16 else 157.3
@@ -423,18 +472,22 @@ def main():
             "metric": "query triplets/sec (forward + similarity + top-k)", "value": world * B * args.steps / dt, "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not args.host_inputs else "synthetic, inputs copied from pinned host memory inside the step",
-            "config": {"workload": f"{args.sam}+{args.siglip}+MaskAdapterPooling, {B} triplets/GPU, {Gtot}-row {args.dtype} gallery"
+            "config": {"workload": (f"BASELINE configs[{args.config}]: {args.config_text} -> " if args.config else "")
+                                   + f"{args.sam}+{args.siglip}+MaskAdapterPooling, {B} triplets/GPU, {Gtot}-row {args.gallery_dtype} gallery"
                                    + (f" sharded {world} ways ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL on one GPU:'} all-gather of queries, host top-k merge)" if world > 1 else ""),
                        "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
             "roofline": {"bound": "mfma", "kernel": ("cor_gemm, bf16 operands: gemm_pp<*> (persistent 256x256 ping-pong, >= 200 tiles) + gemm_tile<bf16,*,128,128> (the rest)" if args.dtype == "bf16" else "cor_gemm, fp32 operands: gemm_tile<float,float,128,128> on v_mfma_f32_32x32x2_f32"), "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, offline pass)", "traffic_source": traffic_note,
+                         "traffic_over_algorithmic": traffic_ratio,
                          "algorithmic_bytes_per_launch": gemm_bytes / max(n_launch, 1), "launches_per_step": n_launch // max(args.steps, 1),
                          "avg_launch_us": gemm_ms * 1e3 / max(n_launch, 1), "gemm_share_of_step": gemm_ms / (dt * 1e3)},
         }
         res["config"]["launch"] = launch_mode
         res["config"]["multimask_output"] = mm
         res["config"]["forwards_in_flight"] = args.inflight if pipe is not None else 1
-        res["config"]["hip_hw_queues"] = int(os.environ["GPU_MAX_HW_QUEUES"])
+        res["config"]["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4 on ROCm 7)")
+        res["config"]["pipeline_stagger"] = bool(pipe.stagger) if pipe is not None else None
+        res["config"]["gallery_dtype"] = args.gallery_dtype
         res["config"]["results"] = ("every step's top-k lists reach the host inside the timed region; step i's lists are awaited and merged after step i + 1 "
                                     "is enqueued (pinned copy behind an event)") if args.defer else "each step's top-k lists are awaited before the next step is enqueued"
         res["roofline"]["events"] = events_from

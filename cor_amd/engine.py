@@ -174,11 +174,15 @@ def pack_mask_decoder(pk: _Packer, q="mask_decoder."):
         pk.lin(f"{q}iou_prediction_head.layers.{j}.")
     # the five output MLPs stacked for ONE launch (cor_decoder_heads); MLP 4 = the IoU head (hidden width 256 like the others: build_model.py's default)
     names = [f"{q}output_hypernetworks_mlps.{i}.layers." for i in range(4)] + [f"{q}iou_prediction_head.layers."]
-    if all(tuple(sd[n + f"{j}.weight"].shape) == (256, 256) for n in names for j in (0, 1)):
-        pk.mat("heads.w01", torch.stack([torch.stack([sd[n + "0.weight"].detach(), sd[n + "1.weight"].detach()]) for n in names]))
-        pk.f32("heads.b01", torch.stack([torch.stack([sd[n + "0.bias"].detach(), sd[n + "1.bias"].detach()]) for n in names]))
-        pk.mat("heads.w2", torch.cat([sd[n + "2.weight"].detach() for n in names], 0))
-        pk.f32("heads.b2", torch.cat([sd[n + "2.bias"].detach() for n in names], 0))
+    # cor_decoder_heads' shapes: hidden width 256 twice, then 4 x [32, 256] (hyper-networks) + [4, 256] (IoU head); anything else keeps
+    # the 15-GEMM path. Keys carry the decoder's prefix (two decoders packed into one W would otherwise collide).
+    last = [tuple(sd[n + "2.weight"].shape) for n in names]
+    if (all(tuple(sd[n + f"{j}.weight"].shape) == (256, 256) for n in names for j in (0, 1))
+            and last == [(32, 256)] * 4 + [(4, 256)]):
+        pk.mat(q + "heads.w01", torch.stack([torch.stack([sd[n + "0.weight"].detach(), sd[n + "1.weight"].detach()]) for n in names]))
+        pk.f32(q + "heads.b01", torch.stack([torch.stack([sd[n + "0.bias"].detach(), sd[n + "1.bias"].detach()]) for n in names]))
+        pk.mat(q + "heads.w2", torch.cat([sd[n + "2.weight"].detach() for n in names], 0))
+        pk.f32(q + "heads.b2", torch.cat([sd[n + "2.bias"].detach() for n in names], 0))
 
 
 def pack(sd: dict, scfg: dict, gcfg: dict, mask_pooling: str, T: torch.dtype) -> dict:
@@ -401,8 +405,8 @@ def mask_decoder(W, emb_tokens, feat, T, multimask_output, all_masks=False, p="m
     hs = _ln(W, tr + "norm_final_attn.", queries, 1e-5, T)                                # [B*6, 256]
 
     # hyper-network MLPs on mask tokens 1..4, IoU head on token 0 (:123-140); rows picked by lda = 6*256
-    if "heads.w01" in W and fused_heads:                                                   # one launch instead of 15 (143 -> ~15 us at batch 32)
-        hyper, iou = ops.decoder_heads(hs, W["heads.w01"], W["heads.b01"], W["heads.w2"], W["heads.b2"])
+    if (p + "heads.w01") in W and fused_heads:                                                   # one launch instead of 15 (143 -> ~15 us at batch 32)
+        hyper, iou = ops.decoder_heads(hs, W[p + "heads.w01"], W[p + "heads.b01"], W[p + "heads.w2"], W[p + "heads.b2"])
     else:
         hs3 = hs.view(B, Tq * C)
         hyper = torch.empty((B, 4, 32), dtype=F32, device=feat.device)
@@ -458,6 +462,13 @@ def forward_support(W, gcfg, mask_pooling, T, support_image_inputs, change_text_
     cur = torch.cuda.current_stream()
     side2 = text_stream
     if side2 is None:
+        if torch.cuda.is_current_stream_capturing():
+            # Under a capture the current stream may itself be a fork of the capture's origin stream; forking again from it made
+            # hipGraph's capture_end crash (ROCm 7.0, profiles/r05_capture_nested_fork_record.txt). The caller did not provide a flat
+            # fork (text_stream), so both towers stay on this stream: same results, no second chain.
+            vis = siglip_vision(W, s_img, gcfg, T)
+            txt = siglip_text(W, change_text_inputs.to(s_img.device), gcfg, T)
+            return support_head(W, vis, txt, s_mask, gcfg, mask_pooling, T)
         side2 = _side_stream(s_img.device, 1)
         side2.wait_stream(cur)
     with torch.cuda.stream(side2):
@@ -484,6 +495,16 @@ def forward_decode(W, scfg, T, emb_tokens, feat, multimask_output=True, return_a
 def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
             multimask_output=True, return_aux=False, overlap_branches=None):
     """ref: lib/sam_with_sup_branch.py:57-104. overlap_branches (None = module default OVERLAP_BRANCHES): per-call choice."""
+    emb_tokens, feat = forward_encode(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_inputs, change_text_inputs,
+                                      support_mask_inputs, overlap_branches)
+    return forward_decode(W, scfg, T, emb_tokens, feat, multimask_output, return_aux)
+
+
+def forward_encode(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
+                   overlap_branches=None):
+    """Everything up to the mask decoder (ref: lib/sam_with_sup_branch.py:76-80): SAM encoder tokens fp32 [B*4096,256] and
+    comb_support_feat fp32 [B,256], both complete on the current stream on return. forward() = forward_encode + forward_decode; the
+    two halves are captured as separate graphs by ForwardPipeline(stagger=True)."""
     if overlap_branches is None:
         overlap_branches = OVERLAP_BRANCHES
     q_img = query_image_inputs.to(F32).contiguous()
@@ -506,4 +527,4 @@ def forward(W, scfg, gcfg, mask_pooling, T, query_image_inputs, support_image_in
     else:
         emb_tokens = sam_encoder(W, q_img, scfg, T)
         feat = forward_support(W, gcfg, mask_pooling, T, support_image_inputs, change_text_inputs, support_mask_inputs, two_chains=False)
-    return forward_decode(W, scfg, T, emb_tokens, feat, multimask_output, return_aux)
+    return emb_tokens, feat

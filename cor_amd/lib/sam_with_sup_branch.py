@@ -105,15 +105,18 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
 
     @torch.no_grad()
     def capture_pipeline(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, multimask_output=True,
-                         depth=2, warmup=2, overlap_branches=True):
+                         depth=2, warmup=2, overlap_branches=True, stagger=True):
         """`depth` captured forwards with their OWN buffers, replayed round-robin on `depth` HIP streams (`ForwardPipeline`): the
         latency-bound end of forward i (support head, mask decoder: ~2.7 ms of small kernels at batch 32) runs beside the encoder
-        GEMMs of forward i + 1 (+2.4 % throughput at batch 32 with depth 2; depth 3 measures lower)."""
+        GEMMs of forward i + 1 (+2.4 % throughput at batch 32 with depth 2; depth 3 measures lower). `stagger` (default True): the
+        replay of slot i + 1 is ordered behind the END OF THE ENCODER of slot i by an event, so two encoders never share the chip
+        whatever the runtime's stream -> hardware-queue mapping is (round 4 got that staggering by accident from GPU_MAX_HW_QUEUES=4:
+        with 8 or 16 queues both forwards advanced in lockstep and a step took 46.3 instead of 42.6 ms)."""
         if self.training:
             raise RuntimeError("cor_amd implements the retrieval-time (inference) forward only: call model.eval() first")
         self._require_gpu()
         return ForwardPipeline(self, (query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs),
-                               multimask_output, depth, warmup, overlap_branches)
+                               multimask_output, depth, warmup, overlap_branches, stagger)
 
     @torch.no_grad()
     def forward_with_aux(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs,
@@ -132,14 +135,17 @@ class GraphedForward:
     as at capture time; CPU tensors are copied over), replays the graph on the current stream and returns the three outputs.
     The outputs are the graph's OWN buffers: they are overwritten by the next replay - pass clone=True to get copies."""
 
-    def __init__(self, model, inputs, multimask_output, warmup, overlap_branches=True):
-        self.model, self.multimask_output, self.calls = model, multimask_output, 0
+    def __init__(self, model, inputs, multimask_output, warmup, overlap_branches=True, split=False):
+        self.model, self.multimask_output, self.calls, self.split = model, multimask_output, 0, split
         dev = model.device
         self.T = model._resolve_dtype()
         self.fingerprint = model._fingerprint()
         with torch.cuda.device(dev):
             self.static_in = [t.detach().to(dev).clone() for t in inputs]
             W = model.packed(self.T)
+            # the graph reads the packed weights BY ADDRESS: hold them, so that a cleared / rebuilt cache (a no-op model.to(dev), a
+            # re-pack after an eager forward) can neither free the memory under the graph nor go unnoticed (ADVICE r4)
+            self.W = W
             args = (W, model.image_encoder.cfg, model.support_branch.siglip.cfg, model.support_branch.mask_pooling_name, self.T)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -150,21 +156,42 @@ class GraphedForward:
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls of OTHER host threads (e.g. a process group's watchdog) must not invalidate the capture
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.static_out = engine.forward(*args, *self.static_in, multimask_output, overlap_branches=overlap_branches)
+            if not split:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.static_out = engine.forward(*args, *self.static_in, multimask_output, overlap_branches=overlap_branches)
+            else:
+                # two graphs over ONE memory pool: [SAM encoder || support branch] and [mask decoder + output layout]; the pipeline
+                # orders the next slot's first graph behind this slot's first graph (ForwardPipeline, stagger)
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self._mid = engine.forward_encode(*args, *self.static_in, overlap_branches=overlap_branches)
+                self.graph_dec = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_dec, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    self.static_out = engine.forward_decode(W, model.image_encoder.cfg, self.T, *self._mid, multimask_output)
 
-    @torch.no_grad()
-    def __call__(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, clone=False):
+    def _check_and_copy(self, inputs):
         self.calls += 1
         if self.model._fingerprint(walk=self.calls % 64 == 1) != self.fingerprint:
             raise RuntimeError("cor_amd: the model's parameters changed (or moved) since capture(): capture again")
+        if self.model._packed.get(self.T) is not self.W:
+            # the cache was dropped (_apply / load_state_dict / invalidate_packed) or rebuilt: the next eager forward would pack NEW
+            # tensors while this graph keeps reading the old ones - same parameters today, silently stale after the next update
+            if self.model._packed.get(self.T) is None and self.model._packed.get("fp") in (None, self.fingerprint):
+                self.model._packed = {"fp": self.fingerprint, **{k: v for k, v in self.model._packed.items() if k != "fp"}, self.T: self.W}
+            else:
+                raise RuntimeError("cor_amd: the model's packed weights were rebuilt since capture(): capture again")
+        for dst, src in zip(self.static_in, inputs):
+            if src.shape != dst.shape:
+                raise ValueError(f"cor_amd: captured for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+
+    @torch.no_grad()
+    def __call__(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, clone=False):
         with torch.cuda.device(self.model.device):
-            for dst, src in zip(self.static_in, (query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs)):
-                if src.shape != dst.shape:
-                    raise ValueError(f"cor_amd: captured for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
-                if src.data_ptr() != dst.data_ptr():
-                    dst.copy_(src, non_blocking=True)
+            self._check_and_copy((query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs))
             self.graph.replay()
+            if self.split:
+                self.graph_dec.replay()
         return tuple(t.clone() for t in self.static_out) if clone else self.static_out
 
 
@@ -174,13 +201,13 @@ class ForwardPipeline:
     submit enqueues (input copy, replay, the caller's `then`) is ordered on that slot's stream, so a slot's buffers are rewritten
     only after whatever `then` enqueued has read them. Results are identical to single forwards (tests/test_gpu_parity.py)."""
 
-    def __init__(self, model, inputs, multimask_output=True, depth=2, warmup=2, overlap_branches=True):
+    def __init__(self, model, inputs, multimask_output=True, depth=2, warmup=2, overlap_branches=True, stagger=True):
         if depth < 1:
             raise ValueError("depth >= 1")
-        self.model, self.n, self.last = model, 0, [None] * depth
+        self.model, self.n, self.last, self.stagger, self.enc_done = model, 0, [None] * depth, bool(stagger) and depth > 1, None
         dev = model.device
         with torch.cuda.device(dev):
-            self.slots = [(GraphedForward(model, inputs, multimask_output, warmup if i == 0 else 1, overlap_branches),
+            self.slots = [(GraphedForward(model, inputs, multimask_output, warmup if i == 0 else 1, overlap_branches, split=self.stagger),
                            torch.cuda.Stream(device=dev)) for i in range(depth)]
 
     def next_inputs(self):
@@ -205,7 +232,20 @@ class ForwardPipeline:
         with torch.cuda.device(dev):
             st.wait_stream(torch.cuda.current_stream(dev))     # inputs written by the caller's stream are complete before the replay
             with torch.cuda.stream(st):
-                out = g(*(inputs if inputs is not None else g.static_in))
+                if not self.stagger:
+                    out = g(*(inputs if inputs is not None else g.static_in))
+                else:
+                    # explicit stagger: this slot's [encoder || support branch] graph starts when the previous submit's has ended (two
+                    # encoders sharing the chip alternate kernel by kernel and both finish late); its decoder then runs beside the NEXT
+                    # submit's encoder. No dependence on how the runtime maps streams to hardware queues.
+                    g._check_and_copy(inputs if inputs is not None else g.static_in)
+                    if self.enc_done is not None:
+                        st.wait_event(self.enc_done)
+                    g.graph.replay()
+                    self.enc_done = torch.cuda.Event()
+                    self.enc_done.record(st)
+                    g.graph_dec.replay()
+                    out = g.static_out
                 res = then(out) if then is not None else None
                 ev = torch.cuda.Event()
                 ev.record(st)

@@ -596,7 +596,7 @@ def test_decoder_heads_one_launch_equals_the_gemm_path(mode, B):
     W = pk.W
     gen = torch.Generator().manual_seed(B)
     hs = (torch.randn((B * 6, 256), generator=gen) * 2).to(mode).to(DEV)
-    hyper, iou = ops.decoder_heads(hs, W["heads.w01"], W["heads.b01"], W["heads.w2"], W["heads.b2"])
+    hyper, iou = ops.decoder_heads(hs, W["mask_decoder.heads.w01"], W["mask_decoder.heads.b01"], W["mask_decoder.heads.w2"], W["mask_decoder.heads.b2"])
     hs3 = hs.view(B, 6 * 256)
     p = "mask_decoder."
     ref_h = torch.empty((B, 4, 32), dtype=F32, device=DEV)
@@ -615,7 +615,7 @@ def test_decoder_heads_one_launch_equals_the_gemm_path(mode, B):
         err = float((got - ref).abs().max())
         _note(name=f"decoder_heads_{name}", mode=str(mode), B=B, max_abs_err=err, scale=scale)
         assert err <= tol * max(scale, 1.0), (name, err, scale)
-    one_h, one_i = ops.decoder_heads(hs[6 * (B - 1):].contiguous(), W["heads.w01"], W["heads.b01"], W["heads.w2"], W["heads.b2"])
+    one_h, one_i = ops.decoder_heads(hs[6 * (B - 1):].contiguous(), W["mask_decoder.heads.w01"], W["mask_decoder.heads.b01"], W["mask_decoder.heads.w2"], W["mask_decoder.heads.b2"])
     assert torch.equal(one_h[0], hyper[B - 1]) and torch.equal(one_i[0], iou[B - 1])
 
 
@@ -1091,9 +1091,10 @@ def test_similarity_small_shard_path_random_shapes():
 
 @pytest.mark.parametrize("Bq,Ng,k,gdt", [(512, 125000, 10, torch.float16), (300, 70001, 5, BF16), (64, 40000, 10, BF16), (512, 3000, 16, BF16)])
 def test_similarity_wave_selection_equals_the_block_selection_kernel(Bq, Ng, k, gdt):
-    """Global-threshold pipeline: the round-4 form (SAMPLE pass converts the queries itself, ballot-counting sim_tau, one-wave-per-query
-    selection with LDS-DMA row staging) against the round-2 form (sim_prep launch + block-per-query sim_final, COR_TOPK_WAVE_FINAL):
-    scores and indices bitwise, and both bitwise against the chain oracle (test_similarity_topk covers the default path)."""
+    """Global-threshold pipeline, the two selection kernels against each other. Default (shipped): sim_prep -> sim_scan<SAMPLE> ->
+    sim_scan<APPEND> (threshold ranked in its prologue from the 32 super-group maxima) -> block-per-query sim_final. Flag
+    COR_TOPK_WAVE_FINAL: the same pipeline ending in sim_final_wave<RECORDS> (one wave per query; measured slower on this pipeline,
+    kept as the A/B partner). Scores and indices bitwise equal, and both bitwise against the chain oracle."""
     ops, _ = _ops()
     from cor_amd import _native as nat
     rng = np.random.default_rng(Bq * 3 + Ng)
@@ -1801,10 +1802,59 @@ def test_graph_captured_forward_equals_eager(mode):
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         g(**utils.synthetic_batch(3, torch.device(DEV), seed=0))
+    # the graph reads the packed weights by address: a no-op model.to(dev) clears the model's cache - the graph holds the
+    # pack alive, the replay is still right and re-installs it (the next eager forward uses the SAME tensors); a cache that was
+    # REBUILT meanwhile (new tensors the graph does not read) is refused
+    W0 = g.W
+    model.to(DEV)
+    assert model._packed.get(mode) is None
+    for a, b in zip(g(**b1, clone=True), e1):
+        assert torch.equal(a, b)
+    assert model._packed.get(mode) is W0 and model.packed(mode) is W0
+    model.invalidate_packed()
+    for a, b in zip(model(**b1, multimask_output=True), e1):         # eager forward re-packs: new tensors
+        assert torch.equal(a, b)
+    assert model._packed.get(mode) is not W0
+    with pytest.raises(RuntimeError, match="rebuilt"):
+        g(**b0)
+    model._packed[mode] = W0                                          # (parameters unchanged: hand the captured pack back)
+    for a, b in zip(g(**b0, clone=True), e0):
+        assert torch.equal(a, b)
     with torch.no_grad():
         next(model.parameters()).add_(1.0)
     with pytest.raises(RuntimeError):
         g(**b0)
+
+
+def test_forward_support_captured_on_a_forked_stream():
+    """engine.forward_support(two_chains=True) called under SOMEONE ELSE's graph capture, on a stream that is itself a fork of the
+    capture stream, without a caller-provided flat fork: a fork of a fork crashed hipGraph's capture_end in round 4
+    (profiles/r05_capture_nested_fork_record.txt); the guard keeps both towers on the current stream. Capture + replay, bit-identical
+    to the eager two-chain result."""
+    from cor_amd.lib.build_model import build_model_with_query_support_feat
+    from cor_amd import utils, engine
+    model = build_model_with_query_support_feat("sam_base", "ViT-B-16-SigLIP-384", None, None, "MaskAdapterPooling")
+    utils.randomize_parameters(model, seed=5)
+    model = model.to(DEV).eval()
+    model.compute_dtype = BF16
+    b = utils.synthetic_batch(2, torch.device(DEV), seed=2)
+    W = model.packed(BF16)
+    gcfg, mp = model.support_branch.siglip.cfg, model.support_branch.mask_pooling_name
+    args = (b["support_image_inputs"], b["change_text_inputs"], b["support_mask_inputs"])
+    want = engine.forward_support(W, gcfg, mp, BF16, *args, two_chains=True).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=DEV)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                                 # a forked stream: forward_support must not fork again from it
+            got = engine.forward_support(W, gcfg, mp, BF16, *args, two_chains=True, text_stream=None)
+        main.wait_stream(side)
+    got.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("depth", [2, 3])
