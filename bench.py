@@ -55,8 +55,9 @@ def parse(argv=None):
                     "explicit flags given after it still win): 1 = SigLIP-B/16 + SAM-B, batch 32, 10k gallery; 2 = the same with a 100k gallery sharded over --gpus ranks; "
                     "3 = SigLIP-L/16-384 + SAM-L, batch 64; 4 = the same with a 1M-row fp16 gallery sharded over --gpus ranks. 0 (default): configs[1]'s model and batch with "
                     "the metric's 100k-row gallery (the headline line)")
-    ap.add_argument("--stagger", type=int, default=1, help="with --inflight > 1: 1 (default) orders a slot's [encoder || support branch] graph behind the previous slot's by an "
-                    "event (ForwardPipeline(stagger=True)); 0: one graph per slot, staggered only by the runtime's stream -> hardware-queue mapping (round 4)")
+    ap.add_argument("--stagger", type=int, default=0, help="with --inflight > 1: 1 orders a slot's [encoder || support branch] graph behind the previous slot's by an "
+                    "event (ForwardPipeline(stagger=True): measured equal at 4 hardware queues, slower at 8 / 16, profiles/r05_pipeline_queues.jsonl); 0 (default): "
+                    "one graph per slot")
     ap.add_argument("--hw-queues", type=int, default=0, help="set GPU_MAX_HW_QUEUES before HIP initialises (0: leave the environment / runtime default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1, 2], help="2: as 1, with the two SigLIP towers as two chains on two streams (round 4); 1: support branch (SigLIP towers, adapter, fusion) beside the SAM encoder: a parallel branch of "
@@ -299,10 +300,11 @@ def main():
     # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). With two forwards in flight the slots' streams and their
     # graph branches SHARE queues, which staggers the two forwards (one's encoder beside the other's tail); with 8 or 16 queues they run in
     # lockstep and a step takes 46.3 instead of 42.6 ms (profiles/r04_pipeline_ab.jsonl, ab10): the measured configuration is pinned.
-    # Round 5: the stagger is explicit (--stagger 1: an event orders consecutive slots' encoder graphs), so the queue count is no longer
-    # pinned: --hw-queues N sets it for A/B runs, otherwise the environment / the runtime's default stands.
-    if args.hw_queues > 0:
-        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+    # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). With two forwards in flight the slots' streams share
+    # queues, which staggers the forwards; with 8 or 16 queues a step is 1.6-2.2 % slower (profiles/r05_pipeline_queues.jsonl; the explicit
+    # event-ordered form, --stagger 1, does not remove that). The measured configuration is the runtime's default, pinned here; --hw-queues N
+    # overrides it for A/B runs; capture_pipeline warns when the environment disagrees.
+    os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues) if args.hw_queues > 0 else os.environ.get("GPU_MAX_HW_QUEUES", "4")
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -485,7 +487,7 @@ def main():
         res["config"]["launch"] = launch_mode
         res["config"]["multimask_output"] = mm
         res["config"]["forwards_in_flight"] = args.inflight if pipe is not None else 1
-        res["config"]["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4 on ROCm 7)")
+        res["config"]["hip_hw_queues"] = int(os.environ["GPU_MAX_HW_QUEUES"])
         res["config"]["pipeline_stagger"] = bool(pipe.stagger) if pipe is not None else None
         res["config"]["gallery_dtype"] = args.gallery_dtype
         res["config"]["results"] = ("every step's top-k lists reach the host inside the timed region; step i's lists are awaited and merged after step i + 1 "

@@ -1,5 +1,7 @@
 """Top-level CORE model on the HIP engine. Same constructor / forward signature / return tuple / state_dict keys as
 the reference's CirSegModelWithQuerySupportFeat (lib/sam_with_sup_branch.py:19-104)."""
+import os
+import warnings
 from typing import Any, List
 
 import torch
@@ -105,13 +107,20 @@ class CirSegModelWithQuerySupportFeat(nn.Module):
 
     @torch.no_grad()
     def capture_pipeline(self, query_image_inputs, support_image_inputs, change_text_inputs, support_mask_inputs, multimask_output=True,
-                         depth=2, warmup=2, overlap_branches=True, stagger=True):
+                         depth=2, warmup=2, overlap_branches=True, stagger=False):
         """`depth` captured forwards with their OWN buffers, replayed round-robin on `depth` HIP streams (`ForwardPipeline`): the
         latency-bound end of forward i (support head, mask decoder: ~2.7 ms of small kernels at batch 32) runs beside the encoder
-        GEMMs of forward i + 1 (+2.4 % throughput at batch 32 with depth 2; depth 3 measures lower). `stagger` (default True): the
-        replay of slot i + 1 is ordered behind the END OF THE ENCODER of slot i by an event, so two encoders never share the chip
-        whatever the runtime's stream -> hardware-queue mapping is (round 4 got that staggering by accident from GPU_MAX_HW_QUEUES=4:
-        with 8 or 16 queues both forwards advanced in lockstep and a step took 46.3 instead of 42.6 ms)."""
+        GEMMs of forward i + 1 (+2.4 % throughput at batch 32 with depth 2; depth 3 measures lower).
+        The gain depends on HOW the two forwards share the chip: with the runtime's default of 4 hardware queues (GPU_MAX_HW_QUEUES) the
+        slots' streams alias onto shared queues and the forwards run staggered (one's encoder beside the other's tail); with 8 or 16
+        queues they advance in lockstep and a step is 1.6-2.2 % slower (round 5, profiles/r05_pipeline_queues.jsonl; 8 % in round 4).
+        `stagger=True` orders a slot's [encoder || support branch] graph behind the previous slot's by an event (two graphs per slot):
+        measured equal at 4 queues and WORSE at 8 / 16 (the decoder chain then really runs beside the next encoder's persistent GEMMs and
+        delays them), so it is off by default and a queue count other than 4 in the environment is reported with a warning."""
+        q = os.environ.get("GPU_MAX_HW_QUEUES")
+        if depth > 1 and q not in (None, "4"):
+            warnings.warn(f"cor_amd.capture_pipeline: GPU_MAX_HW_QUEUES={q}: two forwards in flight were measured 1.6-2.2 % slower per step with 8 or 16 "
+                          "hardware queues than with the runtime's default of 4 (profiles/r05_pipeline_queues.jsonl)", RuntimeWarning, stacklevel=2)
         if self.training:
             raise RuntimeError("cor_amd implements the retrieval-time (inference) forward only: call model.eval() first")
         self._require_gpu()
@@ -201,7 +210,7 @@ class ForwardPipeline:
     submit enqueues (input copy, replay, the caller's `then`) is ordered on that slot's stream, so a slot's buffers are rewritten
     only after whatever `then` enqueued has read them. Results are identical to single forwards (tests/test_gpu_parity.py)."""
 
-    def __init__(self, model, inputs, multimask_output=True, depth=2, warmup=2, overlap_branches=True, stagger=True):
+    def __init__(self, model, inputs, multimask_output=True, depth=2, warmup=2, overlap_branches=True, stagger=False):
         if depth < 1:
             raise ValueError("depth >= 1")
         self.model, self.n, self.last, self.stagger, self.enc_done = model, 0, [None] * depth, bool(stagger) and depth > 1, None
