@@ -1857,8 +1857,8 @@ def test_forward_support_captured_on_a_forked_stream():
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("depth", [2, 3])
-def test_forward_pipeline_equals_single_forwards(depth):
+@pytest.mark.parametrize("depth,stagger", [(2, False), (3, False), (2, True)])
+def test_forward_pipeline_equals_single_forwards(depth, stagger):
     """model.capture_pipeline(): `depth` captured forwards on `depth` streams, consecutive submits overlapping on the GPU (bench.py
     --inflight 2). Twelve submits of three alternating batches, NO host synchronisation in between, every slot's outputs cloned by
     `then` on the slot's stream: each equals the eager forward of its batch bit for bit; the in-place input route (next_inputs)
@@ -1872,7 +1872,8 @@ def test_forward_pipeline_equals_single_forwards(depth):
     names = ("query_image_inputs", "support_image_inputs", "change_text_inputs", "support_mask_inputs")
     batches = [utils.synthetic_batch(2, torch.device(DEV), seed=s) for s in (0, 1, 2)]
     want = [[t.clone() for t in model(**b, multimask_output=True)] for b in batches]
-    pipe = model.capture_pipeline(**batches[0], multimask_output=True, depth=depth)
+    pipe = model.capture_pipeline(**batches[0], multimask_output=True, depth=depth, stagger=stagger)   # stagger: two graphs per slot, encoders chained by an event
+    assert pipe.stagger == stagger and pipe.slots[0][0].split == stagger
     assert len(pipe.slots) == depth and len({st.cuda_stream for _, st in pipe.slots}) == depth
     clone = lambda out: [t.clone() for t in out]                      # noqa: E731 (enqueued on the slot's stream, behind the replay)
     got = [pipe.submit([batches[n % 3][k] for k in names], then=clone) for n in range(12)]
