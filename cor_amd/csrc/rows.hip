@@ -86,6 +86,51 @@ __global__ void __launch_bounds__(256) layernorm_half_kernel(const TI* x, TO* y,
   }
 }
 
+#ifdef COR_PROBES
+// Probe ("bf16 delta"): the residual add moved out of the proj GEMM's epilogue into the LayerNorm pass.
+// x (fp32, in place) += delta (bf16); y = LN(x). Same half-wave-per-row form as layernorm_half_kernel.
+template <int NV, bool WRITE_X>
+__global__ void __launch_bounds__(256) layernorm_delta_probe(float* x, const bf16_t* dl, bf16_t* y, const float* w, const float* b, int rows, int C, float eps) {
+  const int lane = threadIdx.x & 31;
+  const int row = ((int)gridDim.x - 1 - (int)blockIdx.x) * 8 + (threadIdx.x >> 5);
+  if (row >= rows) return;
+  float* xr = x + (long)row * C;
+  const bf16_t* dr = dl + (long)row * C;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = __builtin_nontemporal_load((const f32x4*)(xr + 4 * (lane + 32 * i)));
+    const f32x4 d = ld4<bf16_t>(dr + 4 * (lane + 32 * i));
+    v[i] += d;
+    if (WRITE_X) *(f32x4*)(xr + 4 * (lane + 32 * i)) = v[i];
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  auto hsum = [](float t) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+  };
+  const float mean = hsum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(hsum(q) / C + eps);
+  bf16_t* yr = y + (long)row * C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + 32 * i;
+    const f32x4 wv = *(const f32x4*)(w + 4 * j), bv = *(const f32x4*)(b + 4 * j);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+    st4<bf16_t>(yr + 4 * j, o);
+  }
+}
+#endif
+
 template <typename TI, typename TO>
 int launch_ln(const void* x, void* y, const float* w, const float* b, int rows, int C, float eps, int act, int rev, hipStream_t s) {
   // wide fp32 rows (the residual streams: C = 768 / 1024 / 1152 / 1280): half a wave per row, non-temporal loads (x is read once
@@ -283,6 +328,17 @@ __global__ void __launch_bounds__(256) embed_kernel(const long long* ids, const 
 inline int grid_for(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
 }  // namespace
+
+#ifdef COR_PROBES
+extern "C" int cor_probe_layernorm_delta(void* x, const void* delta, void* y, const float* w, const float* b, int rows, int C, float eps, int write_x, void* stream) {
+  if (C != 768) return COR_ENOSUPPORT;
+  const dim3 g2(cdiv(rows, 8)), b2(256);
+  if (write_x) hipLaunchKernelGGL((layernorm_delta_probe<6, true>), g2, b2, 0, (hipStream_t)stream, (float*)x, (const bf16_t*)delta, (bf16_t*)y, w, b, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_delta_probe<6, false>), g2, b2, 0, (hipStream_t)stream, (float*)x, (const bf16_t*)delta, (bf16_t*)y, w, b, rows, C, eps);
+  COR_CHECK_LAUNCH();
+  return 0;
+}
+#endif
 
 #define DISPATCH2(dt_a, dt_b, CALL)                                             \
   if (dt_a == COR_F32 && dt_b == COR_F32) { CALL(float, float); }               \
