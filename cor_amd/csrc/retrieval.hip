@@ -1004,6 +1004,8 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
   float* thr = cmx + 32 * CS;                          // [QPB]
   int* lcnt = (int*)(thr + QPB);                       // [QPB]
   float* dlt = (float*)(lcnt + QPB);                   // [QPB] delta_q
+  float* smx = dlt + QPB;                              // [QPB] kth: the k-th largest class maximum (the level an overflowing list is re-cut ABOVE)
+  int* lcnt2 = (int*)(smx + QPB);                      // [QPB] entries of the re-cut list
   if (pp == 0) dlt[qq] = SIM_DELTA * fmaxf(1.f, sqrtf(nrm2));
 
   f32x16 acc[QB][T];
@@ -1094,6 +1096,8 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
     float kth = v[0];
 #pragma unroll
     for (int c = 1; c < 32; ++c) kth = (c == k - 1) ? v[c] : kth;
+    smx[lane] = kth;
+    lcnt2[lane] = 0;
     // (fewer than k classes hold a row: -inf, every real row is a candidate; the floor keeps masked -inf scores out with ONE compare)
     thr[lane] = fmaxf(kth - dlt[lane], -3.0e38f);
     lcnt[lane] = 0;
@@ -1106,37 +1110,68 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
   // v_cmp -> s_and_saveexec -> ds_write2_b32 (score, row) -> address += 8 -> restore exec, in inline asm.
   uint2* lst = (uint2*)(smem + ZB);                    // [QPB][cap]
   const unsigned lds_lst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(smem + ZB));
+  // pass 0: everything >= kth - delta. pass 1 (round 5), only for queries whose pass-0 list overflowed: a slice of duplicates ties
+  // hundreds of rows AT its own k-th class maximum for every query; the list is re-cut to the rows strictly ABOVE kth (few: they sit in
+  // fewer than k of the 32 row classes), and kth stays behind as the level of what was left out. sim_final_wave skips the left-out
+  // rows when that level is below the query's short-list cut (exact: every row of the answer has an MFMA score >= the cut), so only a
+  // query the duplicated row is really close to still takes the brute-force path (rounds 1-4: every query of the call did).
+  auto append = [&](const int pass) __attribute__((always_inline)) {
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int ql = qb * 32 + r;
-    float tq = (q0 + ql < Bq) ? thr[ql] : INFINITY;                // padding queries never append
-    int np = 0;
+    for (int qb = 0; qb < QB; ++qb) {
+      const int ql = qb * 32 + r;
+      float tq = (q0 + ql < Bq) ? thr[ql] : INFINITY;              // padding queries never append
+      if (pass == 1) tq = (q0 + ql < Bq && lcnt[ql] > cap) ? __uint_as_float(__float_as_uint(smx[ql]) + (smx[ql] >= 0.f ? 1u : -1u)) : INFINITY;   // next float above kth
+      int* counter = pass == 0 ? lcnt : lcnt2;
+      int np = 0;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) np += acc[qb][t][e] >= tq ? 1 : 0;
-    const int pos0 = np > 0 ? atomicAdd(&lcnt[ql], np) : 0;
-    if (pos0 + np > cap) tq = INFINITY;                            // the list is full: this lane stores nothing; cnt > cap flags the query
-    unsigned addr = lds_lst + (unsigned)(ql * cap + pos0) * 8u;
-    const unsigned rowb = (unsigned)w0 + 4u * h;
+        for (int e = 0; e < 16; ++e) np += acc[qb][t][e] >= tq ? 1 : 0;
+      const int pos0 = np > 0 ? atomicAdd(&counter[ql], np) : 0;
+      if (pos0 + np > cap - pass) tq = INFINITY;                   // the list is full: this lane stores nothing; the count flags the query
+      unsigned addr = lds_lst + (unsigned)(ql * cap + pos0) * 8u;
+      const unsigned rowb = (unsigned)w0 + 4u * h;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const unsigned rowv = rowb + (unsigned)(32 * t + (e & 3) + 8 * (e >> 2));
-        unsigned long long sv;
-        asm volatile("v_cmp_ge_f32 vcc, %2, %3\n\ts_and_saveexec_b64 %1, vcc\n\tds_write2_b32 %0, %2, %4 offset1:1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, %1"
-                     : "+v"(addr), "=&s"(sv) : "v"(acc[qb][t][e]), "v"(tq), "v"(rowv) : "vcc", "memory");
-      }
+        for (int e = 0; e < 16; ++e) {
+          const unsigned rowv = rowb + (unsigned)(32 * t + (e & 3) + 8 * (e >> 2));
+          unsigned long long sv;
+          asm volatile("v_cmp_ge_f32 vcc, %2, %3\n\ts_and_saveexec_b64 %1, vcc\n\tds_write2_b32 %0, %2, %4 offset1:1\n\tv_add_u32 %0, 8, %0\n\ts_mov_b64 exec, %1"
+                       : "+v"(addr), "=&s"(sv) : "v"(acc[qb][t][e]), "v"(tq), "v"(rowv) : "vcc", "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the asm stores are invisible to hipcc's counter bookkeeping
+    __syncthreads();
+  };
+  append(0);
+  {
+    bool over = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) over = over || (q0 + qb * 32 + r < Bq && lcnt[qb * 32 + r] > cap);
+    int* any_over = lcnt2 + QPB;                                   // (inside Z: the kernel's LDS is allocated to the last byte at QB = 2)
+    if (tid == 0) *any_over = 0;
+    __syncthreads();
+    if (over) *any_over = 1;
+    __syncthreads();
+    if (*any_over) append(1);                                      // (block-uniform)
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm stores are invisible to hipcc's counter bookkeeping
-  __syncthreads();
   SB_STAMP();                                          // 5: lists filled
   if (q0 + qq < Bq) {
     const int n_raw = lcnt[qq], n = min(n_raw, cap);
     const long li = (long)(q0 + qq) * nslices + slice;
-    if (pp == 0) cnt[li] = n_raw;                      // > cap: sim_final_wave sees the overflow
-    for (int j = pp; j < n; j += TPQ) cand[li * cap + j] = lst[qq * cap + j];
+    if (n_raw > cap) {
+      // overflow: cnt = cap + 1 + n2 (n2 <= cap - 1 entries strictly above kth follow entry 0 = {kth, marker}); 2 cap + 1: even the re-cut
+      // list overflowed (nothing usable: the query takes the brute-force path)
+      const int n2 = lcnt2[qq];
+      const bool hard = n2 > cap - 1;
+      if (pp == 0) { cnt[li] = hard ? 2 * cap + 1 : cap + 1 + n2; cand[li * cap] = make_uint2(__float_as_uint(smx[qq]), 0xFFFFFFFFu); }
+      if (!hard)
+        for (int j = pp; j < n2; j += TPQ) cand[li * cap + 1 + j] = lst[qq * cap + j];
+    } else {
+      if (pp == 0) cnt[li] = n_raw;
+      for (int j = pp; j < n; j += TPQ) cand[li * cap + j] = lst[qq * cap + j];
+    }
   }
 #ifdef COR_PROBES
   SB_STAMP();                                          // 6: written out
@@ -1174,7 +1209,8 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
     sl_s[lane] = n2;                                   // (parked: read back as delta below, after the barrier)
   }
   int n = 0;
-  bool ovf = false;
+  bool ovf = false, lists_over = false;
+  __shared__ bool sovf[SB_MAXSL];
   if (RECORDS) {
     // 1r. lane <-> stream; record 0 of every stream is fetched TOGETHER with the stream's count (most streams hold 0 or 1 records):
     // one global round trip instead of three dependent ones. Register e of lane half h4 / 4 is row g0 + (e&3) + 8 (e>>2) + h4.
@@ -1239,7 +1275,10 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
     for (int s0 = 0; s0 < nslices; s0 += 64) {
       const int s = s0 + lane;
       int c = s0 == 0 ? c_first : (s < nslices ? cnt[(long)q * nslices + s] : 0);
-      if (c > cap) { ovf = true; c = cap; }
+      // an overflowing list was re-cut by sim_block_scan to the rows strictly above its k-th class maximum (entries 1 ..); entry 0 holds
+      // that level, judged against the cut below
+      if (s < nslices) sovf[s] = c > cap;
+      if (c > cap) { lists_over = true; if (c > 2 * cap) ovf = true; c = c > 2 * cap ? 0 : c - cap - 1; }   // the re-cut list (entries 1 ..), or nothing
       int incl = c;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -1258,7 +1297,7 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
         const int i = min(idx[u], nn - 1);
         int lo = 0, hi = nslices;                          // largest s with soff[s] <= i (empty slices repeat an offset: the search skips them)
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (soff[mid] <= i) lo = mid; else hi = mid; }
-        e[u] = qc[(long)lo * cap + (i - soff[lo])];
+        e[u] = qc[(long)lo * cap + (i - soff[lo]) + (sovf[lo] ? 1 : 0)];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -1307,6 +1346,16 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
       m += __builtin_popcountll(bal);
     }
     if (m > SB_SL) ovf = true;
+    // slices whose lists overflowed: the rows left out of the re-cut list score at most the level in entry 0; they can hold a row of
+    // the answer only if that level reaches the cut (every row of the exact answer has an MFMA score >= cut: the short list's own
+    // criterion). Below it they are skipped - exact; at or above it the query takes the brute-force path as before.
+    if (!RECORDS && __builtin_amdgcn_ballot_w64(lists_over) != 0) {
+      for (int s0 = 0; s0 < nslices; s0 += 64) {
+        const int s = s0 + lane;
+        const bool bad = s < nslices && sovf[s] && !(__uint_as_float(cand[((long)q * nslices + s) * cap].x) < cut);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) ovf = true;
+      }
+    }
   }
   __syncthreads();
   if (ovf) {
@@ -1382,6 +1431,9 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
     p.s_nsplit = cdiv(p.s_tiles, p.s_tiles_per_split);
     p.ngroups = 2 * p.s_nsplit;
     expect = 3L * k * p.s_stride;                      // ~ k * Ng / sample rows, x3 for group-maximum slack
+    // k > 16: tau is the k-th largest of only 32 super-group maxima - near k = 32 their MINIMUM, which admits ~4x the candidates of the
+    // tighter bound the factor 3 was sized for: without this most searches overflow some stream and fall back (exact, slow)
+    if (k > 16) expect *= 4;
     // records per stream: Poisson with mean ~ expect / nstreams (< 1 on large shards); +10 keeps P(overflow) per search < 1e-4
     p.cap = (int)(2 * expect / p.nstreams) + 10;
   }
