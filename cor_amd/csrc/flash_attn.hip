@@ -990,18 +990,22 @@ __global__ void __launch_bounds__(256, 1) flash_global_w64(const FlashArgs a) { 
 
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) {
-    if (!(DBG & 1)) {
-      const unsigned kd = lds0 + (unsigned)((t + 3) & 3) * TILE_B + wofs + 2048u;              // over K(t-1), last read in iteration t-2
-      const unsigned vd = lds0 + K_BYTES + (unsigned)((t + 2) & 3) * TILE_B + wofs + 2048u;    // over V(t-2), last read in iteration t-1
+    // the two copies of a tile under one M0 setting; where in the iteration they are issued is free (their slots were last read one / two
+    // iterations ago): DBG bit 512 = both tiles at the top (the first form), else K beside softmax step 2 and V beside step 10 - measured
+    // equal (2.27 / 2.28 ms); without the copies the kernel takes 1.84 ms: an LDS-DMA instruction costs its wave ~130 cycles wherever it
+    // stands, and at one wave per SIMD nothing else issues meanwhile (register staging - 4 loads + 4 ds_write_b128 per tile - took 2.40)
+    auto dma_tile = [&](const unsigned dst, const unsigned v0, const unsigned v1, const char* src) __attribute__((always_inline)) {
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %3, %5 offset:-2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:2048\n\t"
-                   "s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %6, %8 offset:-2048\n\tglobal_load_lds_dwordx4 %7, %8 offset:2048\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "s"(kd), "s"(vd), "v"(vk0p), "v"(vk1p), "s"(ksrc), "v"(vv0p), "v"(vv1p), "s"(vsrc) : "memory");
-      if (t + 4 < nt) ksrc += tile_bytes;
-      if (t + 3 < nt) vsrc += tile_bytes;
-    }
+                   "global_load_lds_dwordx4 %2, %4 offset:-2048\n\tglobal_load_lds_dwordx4 %3, %4 offset:2048\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(dst), "v"(v0), "v"(v1), "s"(src) : "memory");
+    };
+    const unsigned kd = lds0 + (unsigned)((t + 3) & 3) * TILE_B + wofs + 2048u;                // over K(t-1), last read in iteration t-2
+    const unsigned vd = lds0 + K_BYTES + (unsigned)((t + 2) & 3) * TILE_B + wofs + 2048u;      // over V(t-2), last read in iteration t-1
+    const char *ksrc_t = ksrc, *vsrc_t = vsrc;
+    if (t + 4 < nt) ksrc += tile_bytes;
+    if (t + 3 < nt) vsrc += tile_bytes;
+    if (!(DBG & 1) && (DBG & 512)) { dma_tile(kd, vk0p, vk1p, ksrc_t); dma_tile(vd, vv0p, vv1p, vsrc_t); }
     const char *Vs = Vring + ((t + 3) & 3) * TILE_B, *Ks = Kring + ((t + 1) & 3) * TILE_B;   // V(t-1), K(t+1)
     const float rh0 = aux[t * 64 + r], rh1 = aux[t * 64 + 32 + r];
     u32x4 vf[8], kf[8];
@@ -1087,6 +1091,10 @@ __global__ void __launch_bounds__(256, 1) flash_global_w64(const FlashArgs a) { 
         for (int i = 0; i < 2; ++i) pn[i] = (DBG & 8) ? s[qb][kb][e0 + i] - msub[qb] : (DBG & 256) ? __builtin_amdgcn_exp2f(s[qb][kb][e0 + i]) : __builtin_amdgcn_exp2f(s[qb][kb][e0 + i] - msub[qb]);
       }
       if (c > 0) { d0 = pk2(pe[0], pe[1]); if (!(DBG & 128)) lsum[qbp][k4 & 1] = sum2_bf16(d0, lsum[qbp][k4 & 1]); else if (c == 1) lsum[qbp][k4 & 1] += __uint_as_float(d0); }
+      if (!(DBG & 1) && !(DBG & 512)) {
+        if (c == 2) dma_tile(kd, vk0p, vk1p, ksrc_t);
+        if (c == 10) dma_tile(vd, vv0p, vv1p, vsrc_t);
+      }
       // first MFMA of the step
       if (c < 4) pv(2 + 2 * c);
       else if (c < 8) pv(6 + c);
@@ -1479,7 +1487,7 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
   const int rev = (variant & COR_ORDER_REVERSE) ? 1 : 0;
   variant &= ~COR_ORDER_REVERSE;
 #ifdef COR_PROBES
-  if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 9 && !(variant >= 16 && variant < 1024)) return COR_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 9 && !(variant >= 16 && variant < 4096)) return COR_EINVAL;
 #else
   if (variant != 0 && variant != 1 && variant != 2 && variant != 4) return COR_EINVAL;   // no probe / experimental kernels in the production library
 #endif
@@ -1513,6 +1521,7 @@ int cor_flash_sam_bf16(const void* qkv, void* out, int out_dtype, const void* pa
         case 128: return launch_global_w64<bf16_t, 128>(a, B, s);
         case 256: return launch_global_w64<bf16_t, 256>(a, B, s);
         case 384: return launch_global_w64<bf16_t, 384>(a, B, s);
+        case 512: return launch_global_w64<bf16_t, 512>(a, B, s);
         default: return COR_EINVAL;
       }
     }

@@ -15,7 +15,7 @@ pad = torch.randn((3 * d,), device=dev).to(T)
 rh = torch.randn((127, 64), device=dev) * 0.5
 rw = torch.randn((127, 64), device=dev) * 0.5
 names = {0: "w64", 2: "pipe", 17: "-copies", 18: "-wait/barrier", 19: "-copies-barrier", 20: "-fragment reads", 23: "-copies-barrier-reads", 24: "-exp2", 32: "-max",
-         48: "-PV mfma", 80: "-QK mfma", 112: "-all mfma", 143: "-everything", 144: "-rowsum", 272: "-sub", 400: "-rowsum-sub", 3: "pipe+CB"}
+         48: "-PV mfma", 80: "-QK mfma", 112: "-all mfma", 143: "-everything", 144: "-rowsum", 272: "-sub", 400: "-rowsum-sub", 3: "pipe+CB", 528: "w64 copies at top", 4: "w64", 1040: "w64 register staging"}
 variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(names)
 for rnd in range(2):
     for v in variants:
