@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(s[kb][e] - msub);
       // row sums on the VALU (this lane's 16 keys of the block; the lane halves are added once at the end): beside MFMAs a
-      // vector instruction costs ~2 cycles, a ones-row MFMA 32 (profiles/r02_valu_mfma_issue_probe.jsonl)
+      // vector instruction costs ~2 cycles, a ones-row MFMA 32 (profiles/archive/r02_valu_mfma_issue_probe.jsonl)
       lsum[1] += (p[0] + p[1]) + (p[2] + p[3]); lsum[2] += (p[4] + p[5]) + (p[6] + p[7]);
       lsum[1] += (p[8] + p[9]) + (p[10] + p[11]); lsum[2] += (p[12] + p[13]) + (p[14] + p[15]);
       pf[kb][0] = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd(const FlashArgs a) {
 //     had one iteration, about its own global-load latency); one counted wait and one barrier per iteration.
 // LDS = 48 KiB rings + 32 KiB row-bias tables = 80 KiB: two blocks per CU. Tile -1 is a zero V tile with P = 0; the last
 // iteration's S(nt) comes from a stale K tile and is dropped.
-// Variants tried and measured slower (round 2, profiles/r02_attention_fold_ablation.jsonl, r02_attention_pingpong_stamps.jsonl; their
+// Variants tried and measured slower (round 2, profiles/archive/r02_attention_fold_ablation.jsonl, r02_attention_pingpong_stamps.jsonl; their
 // code is in the history up to commit 5d3e0f7): bias / running reference as extra k-steps of the score MFMA (+1 % / +12 %), 8-wave
 // blocks (+5 %), an explicit ping-pong form with alternating matrix / softmax segments (+5 %), row sums of P by a ones-row MFMA (+4 %).
 // STAMP (COR_PROBES builds only, tools/attn_stamps.py): per-section cycle sums are written INSTEAD of the outputs.

@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
   // in that XCD's 4-MiB L2 for a whole sweep over M and only the A-panels stream (N = 768: one group, every A-panel is fetched once).
   // The round-2 order (g.order == 0: bands of GM M-panels, tiles dealt to the XCDs in chunks of 32 per step of 256) gave every XCD
   // 8 new A-panels AND 4 new W-panels at every step: L2 read traffic 4.2x (qkv, lin1) / 1.5x (lin2) the algorithmic bytes
-  // (FETCH_SIZE, profiles/r03_gemm_pmc_by_shape.jsonl).
+  // (FETCH_SIZE, profiles/archive/r03_gemm_pmc_by_shape.jsonl).
   const int per_xcd = (total + 7) >> 3;
   auto tile_of = [&](int q) -> int {               // q-th tile of this block, or -1
     if (g.order == 0) { const int t = xcd_remap(blockIdx.x, G) + q * G; return t < total ? t : -1; }
@@ -895,7 +895,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.order = 1;                                       // resolved below (persistent kernel only): see set_tile
   // bf16 outputs of the persistent kernel are stored non-temporally: with the whole-line epilogue every store instruction writes
   // complete 128-byte lines, nothing is left for a cache to merge, and as plain stores the C stream evicts the A / W panels the K
-  // loops re-read from L2 (tools/gemm_store_policy_ab.py: qkv 464 -> 436 us, lin1+GELU 685 -> 644 us on the box where it mattered;
+  // loops re-read from L2 (tools/archive/gemm_store_policy_ab.py: qkv 464 -> 436 us, lin1+GELU 685 -> 644 us on the box where it mattered;
   // bench A/B of the final build, two alternating rounds: no nt 711 / 712, nt for outputs >= 256 MiB 713 / 720, nt for all 724 / 726
   // triplets/s). fp32 residual outputs keep the default policy (the next LayerNorm re-reads them out of the Infinity Cache).
   g.nt_c = (sizeof(TO) == 2 && !residual) ? 1 : 0;
@@ -907,7 +907,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
     cfg = (k128 && M >= 512 && N >= 64) ? ((N <= 256 && K >= 2048 && M >= 65536) ? 9 : COR_GEMM_DEFAULT_BIG) : 1;
-    // persistent 256x256 ping-pong kernel once its tiles cover most CUs (tools/gemm_bench.py, profiles/r01_gemm_pingpong.txt:
+    // persistent 256x256 ping-pong kernel once its tiles cover most CUs (tools/gemm_bench.py, profiles/archive/r01_gemm_pingpong.txt:
     // +9..45 % from 216 tiles up, -12 % at 72-128 tiles)
     // small GEMMs (text tower, 2048 rows): 64x64 tiles put 4x the blocks on the 256 CUs (+16..25 % at N = 768, nothing at N >= 2304)
     if (cfg == 2 && (long)cdiv(M, 128) * cdiv(N, 128) < 128) cfg = 4;
@@ -926,7 +926,7 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
       // once (L2 read traffic 1.39 -> 1.17x / 1.16 -> 1.07x of the algorithmic bytes at equal time). Wider GEMMs keep the banded order:
       // there the W-panels do not survive in L2 beside the A and C streams, the L2 traffic is unchanged (1.7-1.8x, served by the
       // Infinity Cache: the XCDs of a band fetch the same A-panels at the same time) and the sweeps of different XCDs over M drift
-      // apart, which costs 2-5 % (tools/gemm_order_ab.py, profiles/r03_gemm_tile_order_ab.jsonl).
+      // apart, which costs 2-5 % (tools/archive/gemm_order_ab.py, profiles/archive/r03_gemm_tile_order_ab.jsonl).
       g.order = g.tn <= 4 ? 1 : 0;
       if (g_gemm_dbg & 0x1000) g.order ^= 1;         // COR_PROBES A/B (cfg bit 20); production callers cannot set it
       static DevOnce once_a;

@@ -224,7 +224,7 @@ def sam_encoder(W, img, cfg, T, p="image_encoder."):
     # Work order along the chain: the GEMMs write their outputs from the first row panel to the last, so the kernels that
     # consume a GEMM's output (LayerNorm over the 403 MB residual, attention over the 604 MB qkv) walk it from the LAST row to
     # the first - they start on the ~200 MB the producer left in the 256 MB Infinity Cache and finish on the low rows, where
-    # the next GEMM starts (measured +0.5 ... +2.5 % end to end depending on the box, profiles/r02_work_order_ab.txt).
+    # the next GEMM starts (measured +0.5 ... +2.5 % end to end depending on the box, profiles/archive/r02_work_order_ab.txt).
     for i in range(cfg["depth"]):
         b = f"{p}blocks.{i}."
         win = 0 if i in cfg["global_idx"] else cfg["window"]

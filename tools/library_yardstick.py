@@ -2,7 +2,7 @@
 """Yardstick (not a product path): the vendor libraries reached through torch (hipBLASLt / rocBLAS GEMM, the SDPA flash kernel) on the
 batch-32 SAM-B block shapes, beside the hand-written kernels WITH their fused epilogues. The library numbers are for the bare
 product (bf16 C = A·W^T [+ bias]); the residual add / GELU / fp32 output the hand-written epilogue does would be further kernels.
-Output: JSON lines (profiles/r03_library_yardstick.jsonl)."""
+Output: JSON lines (profiles/archive/r03_library_yardstick.jsonl)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

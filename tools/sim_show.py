@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the similarity measurement pass of tools/measure_r04_sim.sh (gpurun_out/r4s): back-to-back times per path and per-kernel averages."""
+"""Print the similarity measurement pass of tools/archive/measure_r04_sim.sh (gpurun_out/r4s): back-to-back times per path and per-kernel averages."""
 import csv, glob, json, os, sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r4s"
 rows = {}
