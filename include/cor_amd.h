@@ -95,8 +95,11 @@ int cor_sam_attention(const void* qkv, int dtype, void* out, int out_dtype, cons
  * no per-score multiply - the engine folds it into the q rows of the qkv weight / bias at pack time, so it costs nothing at
  * run time and q is rounded to bf16 once. The rel-pos terms are rescaled accordingly inside (they use the unscaled q).
  * `variant` is a PER-CALL kernel choice for the bf16 MFMA path: 0 = default kernels (global: flash_global_pipe, software-
- * pipelined over key tiles; windowed: win_attn, one 7-wave block per (window, head)); 1 = the round-1 chain forms of the same
- * arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the in-process A/B and parity partners (tests, tools/attn_bench.py);
+ * pipelined over key tiles, with a pre-scaled q the column bias is the score MFMA's start value; windowed: win_attn, one 7-wave
+ * block per (window, head)); 1 = the round-1 chain forms of the same arithmetic (flash_fwd<1> / flash_fwd<2>), kept as the
+ * in-process A/B and parity partners (tests, tools/attn_bench.py); 2 = flash_global_pipe with the bias as one fma per score
+ * (round 4's default; A/B partner); 4 = flash_global_w64 (global, pre-scaled q only: 64 queries per wave at one wave per SIMD;
+ * parity-tested, measured slower: DESIGN 3.2); 2 and 4 select the default kernel where they do not apply (windowed, raw q);
  * optionally | COR_ORDER_REVERSE. Anything else is COR_EINVAL (the timing probe of the global kernel, which writes cycle
  * counters instead of outputs, exists in -DCOR_PROBES builds only: tools/probes/libcor_probes.so, tools/attn_stamps.py). */
 
