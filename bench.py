@@ -478,7 +478,7 @@ def main():
                                    + f"{args.sam}+{args.siglip}+MaskAdapterPooling, {B} triplets/GPU, {Gtot}-row {args.gallery_dtype} gallery"
                                    + (f" sharded {world} ways ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL on one GPU:'} all-gather of queries, host top-k merge)" if world > 1 else ""),
                        "global_batch": world * B, "gallery_rows": Gtot, "topk": args.topk, "parallelism": f"dp{world}+gallery-shard{world}"},
-            "roofline": {"bound": "mfma", "kernel": ("cor_gemm, bf16 operands: gemm_pp<*> (persistent 256x256 ping-pong, >= 200 tiles) + gemm_tile<bf16,*,128,128> (the rest)" if args.dtype == "bf16" else "cor_gemm, fp32 operands: gemm_tile<float,float,128,128> on v_mfma_f32_32x32x2_f32"), "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": ("cor_gemm, bf16 operands: gemm_pp<*> (persistent 256x256 ping-pong, >= 140 tiles) + gemm_tile<bf16,*,128,128> (the rest)" if args.dtype == "bf16" else "cor_gemm, fp32 operands: gemm_tile<float,float,128,128> on v_mfma_f32_32x32x2_f32"), "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, offline pass)", "traffic_source": traffic_note,
                          "traffic_over_algorithmic": traffic_ratio,
                          "algorithmic_bytes_per_launch": gemm_bytes / max(n_launch, 1), "launches_per_step": n_launch // max(args.steps, 1),

@@ -16,7 +16,7 @@
 //     per-lane SOURCE chunk; GLDS = true), double buffered, one barrier per K-step; the register-staged form
 //     (global_load_dwordx4 for tile t+1 issued before the MFMAs of tile t, ds_write after them; GLDS = false) remains for
 //     K tails that direct-to-LDS staging cannot zero-fill and for unaligned operands;
-//   * gemm_pp (further down): persistent 256x256 ping-pong kernel for >= 200 output tiles (see its own header);
+//   * gemm_pp (further down): persistent 256x256 ping-pong kernel for >= 140 output tiles (see its own header);
 //   * XCD-aware tile order: blocks that share an XCD walk N-tiles of the same A row-panel (L2 reuse of A).
 #include "common.h"
 
@@ -907,12 +907,22 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
     cfg = (k128 && M >= 512 && N >= 64) ? ((N <= 256 && K >= 2048 && M >= 65536) ? 9 : COR_GEMM_DEFAULT_BIG) : 1;
+    // few rows (text tower at batch 1-4: M = 64..256; the decoder's token rows: M = 6..192): the 64x64 LDS-DMA kernel instead of the
+    // register-staged 128x128 one: 13 -> 6 us at 64 x 2304 x 768, 39.5 -> 15.5 at 64 x 768 x 3072, 27 -> 10.6 at 6 x 256 x 2048 (device
+    // time under graph replay, bit-identical results: every tile kernel accumulates K in the same order; tools/gemm_small_m.py,
+    // profiles/r05_gemm_small_m.jsonl). The batch-1 forward's critical path is the text tower's chain of 48 such launches.
+    if (k128 && M < 512 && N >= 64) cfg = 4;
     // persistent 256x256 ping-pong kernel once its tiles cover most CUs (tools/gemm_bench.py, profiles/archive/r01_gemm_pingpong.txt:
     // +9..45 % from 216 tiles up, -12 % at 72-128 tiles)
     // small GEMMs (text tower, 2048 rows): 64x64 tiles put 4x the blocks on the 256 CUs (+16..25 % at N = 768, nothing at N >= 2304)
-    if (cfg == 2 && (long)cdiv(M, 128) * cdiv(N, 128) < 128) cfg = 4;
+    // (round 5, device time under graph replay, tools/gemm_small_m.py mid: 4096 x 768 x 768 13.9 -> 11.6 us and 4096 x 768 x 3072 38.4 -> 32.8 at
+    // 192 tiles of 128 x 128; 8192 x 768 at 384 tiles keeps the 128 x 128 kernel)
+    if (cfg == 2 && (long)cdiv(M, 128) * cdiv(N, 128) < 256) cfg = 4;
     // (and N fills at least 3/4 of its 256-wide tiles: at N = 128 the half-empty tile loses 10 % to the 128x128 kernel)
-    if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 200 && 4L * N >= 3L * 256 * cdiv(N, 256)) cfg = 13;
+    // (round 5: the persistent kernel already wins at 144 and 192 tiles - the batch-1 encoder's qkv 4096 x 2304 x 768 28.9 -> 20.7 us, lin1
+    // 33.6 -> 25.1, the batch-4 encoder's proj / lin2 at 192 tiles 37.7 -> 31.8 / 96.2 -> 75.4 - and loses at 96 and 48:
+    // profiles/r05_gemm_mid_m.jsonl; the threshold was 200)
+    if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 140 && 4L * N >= 3L * 256 * cdiv(N, 256)) cfg = 13;
   }
   if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
   if (cfg == 13 || cfg == 14) {
