@@ -918,11 +918,12 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
     // (round 5, device time under graph replay, tools/gemm_small_m.py mid: 4096 x 768 x 768 13.9 -> 11.6 us and 4096 x 768 x 3072 38.4 -> 32.8 at
     // 192 tiles of 128 x 128; 8192 x 768 at 384 tiles keeps the 128 x 128 kernel)
     if (cfg == 2 && (long)cdiv(M, 128) * cdiv(N, 128) < 256) cfg = 4;
+    else if (cfg == 2 && (long)cdiv(M, 128) * cdiv(N, 128) < 512) cfg = 3;   // 2048 x 2304 / 3072 x 768 (text tower, batch 32), 8192 x 768: 128 x 64 tiles, -4 ... -8 %
     // (and N fills at least 3/4 of its 256-wide tiles: at N = 128 the half-empty tile loses 10 % to the 128x128 kernel)
     // (round 5: the persistent kernel already wins at 144 and 192 tiles - the batch-1 encoder's qkv 4096 x 2304 x 768 28.9 -> 20.7 us, lin1
     // 33.6 -> 25.1, the batch-4 encoder's proj / lin2 at 192 tiles 37.7 -> 31.8 / 96.2 -> 75.4 - and loses at 96 and 48:
     // profiles/r05_gemm_mid_m.jsonl; the threshold was 200)
-    if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 140 && 4L * N >= 3L * 256 * cdiv(N, 256)) cfg = 13;
+    if (sizeof(TA) == 2 && k128 && !col_scale && (long)cdiv(M, 256) * cdiv(N, 256) >= 140 && 4L * N >= 3L * 256 * cdiv(N, 256) && K >= 256) cfg = 13;   // (K = 128: 131072 x 256 x 128 50.8 vs 45.1 us)
   }
   if (!k128 && (cfg == 2 || cfg == 3 || cfg == 4)) cfg = 1;
   if (cfg == 13 || cfg == 14) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Throughput of the benchmarked path over the per-GPU batch and the number of forwards in flight (serving view): bench.py --batch B
-# --inflight F, hipGraph replay, one GPU. Output: gpurun_out/sweep/batch_sweep.jsonl -> profiles/r04_batch_sweep.jsonl
+# --inflight F, hipGraph replay, one GPU. Output: gpurun_out/sweep/batch_sweep.jsonl -> profiles/r05_batch_sweep.jsonl
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/sweep; mkdir -p $O; : > $O/batch_sweep.jsonl
 cd $R
 for B in 1 2 4 8 16 32 64; do

@@ -19,6 +19,9 @@ def t(f, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 SHAPES = ((4096, 2304, 768, "plain"), (4096, 768, 768, "res"), (4096, 3072, 768, "gelu"), (4096, 768, 3072, "res"), (8192, 2304, 768, "plain"), (8192, 768, 768, "res"), (8192, 3072, 768, "gelu"), (8192, 768, 3072, "res"),
           (16384, 768, 768, "res"), (16384, 768, 3072, "res"), (1152, 768, 768, "res"), (1152, 768, 3072, "res"), (1152, 2304, 768, "plain"), (2304, 768, 3072, "res")) if len(sys.argv) > 1 and sys.argv[1] == "mid" else None
+if len(sys.argv) > 1 and sys.argv[1] == "b32":   # the batch-32 step's inefficient launches (profiles/r05_gemm_shapes.jsonl)
+    SHAPES = ((2048, 768, 3072, "res"), (2048, 3072, 768, "gelu"), (2048, 2304, 768, "plain"), (2048, 768, 768, "res"), (18432, 768, 768, "res"), (18432, 768, 3072, "res"),
+              (18432, 2304, 768, "plain"), (18432, 3072, 768, "gelu"), (131072, 128, 256, "plain"), (131072, 256, 128, "res"), (18432, 1024, 256, "gelu"), (18432, 256, 1024, "res"))
 for (M, N, K, mode) in SHAPES or ((64, 2304, 768, "plain"), (64, 768, 768, "res"), (64, 3072, 768, "gelu"), (64, 768, 3072, "res"), (128, 2304, 768, "plain"), (256, 768, 3072, "res"),
                         (6, 256, 256, "plain"), (6, 256, 2048, "res"), (6, 2048, 256, "gelu"), (192, 256, 2048, "res"), (192, 256, 256, "plain"), (576, 2304, 768, "plain"), (576, 768, 3072, "res")):
     A = torch.randn((M, K), device="cuda").to(BF); W = (torch.randn((N, K), device="cuda") / K ** 0.5).to(BF)
