@@ -160,19 +160,91 @@ __global__ void __launch_bounds__(NT) attn_rowlane(const AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// attn_fewq: a handful of queries (<= 8) against thousands of keys - the decoder's token -> image cross attention
-// (6 tokens x 4096 image keys, 8 heads x 16; lib/sam_model/transformer.py:163-166,99-100). One query per lane would leave 58 of 64
-// lanes idle and walk 4096 keys serially (measured 2.6 ms per launch); here the KEYS are spread over the lanes of a block (one block
-// per (batch, head)), every lane keeps a private online-softmax state, and the partial states are merged once at the end (wave
-// shuffles, then LDS).
-// Round 5: 16 waves per block, TWO waves per query (128 key lanes each): a lane walks Tk / 128 keys with ONE query's state (the first form
-// gave every lane all 8 queries and Tk / 256 keys: 300 dependent vector instructions per key, 40 us per launch however few blocks there
-// were - at batch 1 this kernel runs three times on the forward's critical path). The keys are re-read by the 8 queries' waves out of L1 / L2.
+// attn_fewq: a handful of queries (<= 8) against thousands of keys — the decoder's token -> image cross attention
+// (6 tokens x 4096 image keys, 8 heads x 16; lib/sam_model/transformer.py:163-166,99-100). One query per lane would
+// leave 58 of 64 lanes idle and walk 4096 keys serially (measured 2.6 ms per launch); here the KEYS are spread over
+// the 256 lanes of a block (one block per (batch, head)), every lane keeps a private online-softmax state for all
+// queries, and the partial states are merged once at the end (wave shuffles, then LDS across the 4 waves).
 template <typename T, typename TO, int HD, int TQ>
-__global__ void __launch_bounds__(128 * TQ) attn_fewq(const AttnArgs a) {
-  __shared__ float red[2 * TQ][HD + 2];
+__global__ void __launch_bounds__(256) attn_fewq(const AttnArgs a) {
+  __shared__ float qs[TQ][HD];
+  __shared__ float red[4][TQ][HD + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const T* qb = (const T*)a.q + b * a.q_sb + h * HD;
+  const T* kb = (const T*)a.k + b * a.k_sb + h * HD;
+  const T* vb = (const T*)a.v + b * a.v_sb + h * HD;
+  for (int i = tid; i < TQ * HD; i += 256) {
+    const int qi = i / HD, d = i - qi * HD;
+    qs[qi][d] = qi < a.Tq ? ld<T>(qb + (long)qi * a.q_st + d) * a.scale : 0.f;
+  }
+  __syncthreads();
+  float m[TQ], l[TQ], o[TQ][HD];
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    m[qi] = -INFINITY; l[qi] = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[qi][d] = 0.f;
+  }
+  for (int j = tid; j < a.Tk; j += 256) {
+    float kv[HD], vv[HD];
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+      const f32x4 k4 = ld4<T>(kb + (long)j * a.k_st + 4 * i), v4 = ld4<T>(vb + (long)j * a.v_st + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kv[4 * i + e] = k4[e]; vv[4 * i + e] = v4[e]; }
+    }
+#pragma unroll
+    for (int qi = 0; qi < TQ; ++qi) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) sc = fmaf(qs[qi][d], kv[d], sc);
+      const float mn = fmaxf(m[qi], sc);
+      const float alpha = __expf(m[qi] - mn), p = __expf(sc - mn);
+      l[qi] = l[qi] * alpha + p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[qi][d] = fmaf(p, vv[d], o[qi][d] * alpha);
+      m[qi] = mn;
+    }
+  }
+  // merge the 64 lane states of a wave, then the 4 waves
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    const float mw = wave_max(m[qi]);
+    const float f = m[qi] == -INFINITY ? 0.f : __expf(m[qi] - mw);
+    const float lw = wave_sum(l[qi] * f);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[qi][d] = wave_sum(o[qi][d] * f);
+    if (lane == 0) {
+      red[wave][qi][HD] = mw; red[wave][qi][HD + 1] = lw;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) red[wave][qi][d] = o[qi][d];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.Tq * HD; i += 256) {
+    const int qi = i / HD, d = i - qi * HD;
+    float mm = -INFINITY;
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[w][qi][HD]);
+    float num = 0.f, den = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      const float f = red[w][qi][HD] == -INFINITY ? 0.f : __expf(red[w][qi][HD] - mm);
+      num += red[w][qi][d] * f; den += red[w][qi][HD + 1] * f;
+    }
+    st<TO>((TO*)a.o + b * a.o_sb + (long)qi * a.o_st + h * HD + d, num / den);
+  }
+}
+
+// Round 5, the same arithmetic for SMALL grids (B * H < 128 blocks: batch 1..15, where this kernel sits three times on the forward's
+// critical path and a lane's chain of 16 keys x 8 queries x ~38 dependent instructions takes 40 us however few blocks run): one thread per
+// (query, key slot) instead of one per key slot - 4 queries x 256 slots = 16 waves per block, two blocks per (batch, head). Slot s still
+// walks keys s, s + 256, ... in order, a wave still merges the same 64 slots by the same butterflies and the four waves of a query are
+// merged in the same order, so the result is BIT-IDENTICAL to attn_fewq (a sample's output does not depend on the batch size).
+template <typename T, typename TO, int HD, int TQ>
+__global__ void __launch_bounds__(1024) attn_fewq_wide(const AttnArgs a) {
+  __shared__ float red[16][HD + 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qi = wave >> 1, kl = (wave & 1) * 64 + lane;              // this wave's query, this lane's key slot (0..127)
+  const int qi = (wave >> 2) + (TQ / 2) * blockIdx.z, slot = (wave & 3) * 64 + lane;
   const int h = blockIdx.x, b = blockIdx.y;
   const T* qb = (const T*)a.q + b * a.q_sb + h * HD;
   const T* kb = (const T*)a.k + b * a.k_sb + h * HD;
@@ -184,7 +256,7 @@ __global__ void __launch_bounds__(128 * TQ) attn_fewq(const AttnArgs a) {
 #pragma unroll
   for (int d = 0; d < HD; ++d) o[d] = 0.f;
   if (qi < a.Tq) {                                                     // (wave-uniform)
-    for (int j = kl; j < a.Tk; j += 128) {
+    for (int j = slot; j < a.Tk; j += 256) {
       float kv[HD], vv[HD];
 #pragma unroll
       for (int i = 0; i < HD / 4; ++i) {
@@ -203,7 +275,6 @@ __global__ void __launch_bounds__(128 * TQ) attn_fewq(const AttnArgs a) {
       m = mn;
     }
   }
-  // merge the 64 lane states of a wave, then the two waves of the query
   {
     const float mw = wave_max(m);
     const float f = m == -INFINITY ? 0.f : __expf(m - mw);
@@ -217,19 +288,24 @@ __global__ void __launch_bounds__(128 * TQ) attn_fewq(const AttnArgs a) {
     }
   }
   __syncthreads();
-  for (int i = tid; i < a.Tq * HD; i += 128 * TQ) {
-    const int qq = i / HD, d = i - qq * HD;
-    const float m0 = red[2 * qq][HD], m1 = red[2 * qq + 1][HD];
-    const float mm = fmaxf(m0, m1);
-    const float f0 = m0 == -INFINITY ? 0.f : __expf(m0 - mm), f1 = m1 == -INFINITY ? 0.f : __expf(m1 - mm);
-    const float num = red[2 * qq][d] * f0 + red[2 * qq + 1][d] * f1, den = red[2 * qq][HD + 1] * f0 + red[2 * qq + 1][HD + 1] * f1;
+  for (int i = tid; i < (TQ / 2) * HD; i += 1024) {
+    const int ql = i / HD, d = i - ql * HD, qq = ql + (TQ / 2) * blockIdx.z;
+    if (qq >= a.Tq) continue;
+    float mm = -INFINITY;
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[4 * ql + w][HD]);
+    float num = 0.f, den = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      const float f = red[4 * ql + w][HD] == -INFINITY ? 0.f : __expf(red[4 * ql + w][HD] - mm);
+      num += red[4 * ql + w][d] * f; den += red[4 * ql + w][HD + 1] * f;
+    }
     st<TO>((TO*)a.o + b * a.o_sb + (long)qq * a.o_st + h * HD + d, num / den);
   }
 }
 
 template <typename T, typename TO>
 int launch_fewq(const AttnArgs& a, int B, hipStream_t s) {
-  hipLaunchKernelGGL((attn_fewq<T, TO, 16, 8>), dim3(a.H, B), dim3(1024), 0, s, a);
+  if ((long)a.H * B < 128) hipLaunchKernelGGL((attn_fewq_wide<T, TO, 16, 8>), dim3(a.H, B, 2), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL((attn_fewq<T, TO, 16, 8>), dim3(a.H, B), dim3(256), 0, s, a);
   COR_CHECK_LAUNCH();
   return 0;
 }

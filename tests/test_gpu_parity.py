@@ -377,6 +377,28 @@ def test_attention_online_softmax_rescale(T):
     report(f"attention_rescale_{T}", out, ref, **(dict(rtol=1e-4, atol=1e-4) if T == F32 else dict(rtol=2e-2, atol=2e-2)))
 
 
+@pytest.mark.parametrize("T", [BF16, F32])
+def test_decoder_cross_attention_small_grid_kernel_is_bit_identical(T):
+    """The decoder's token -> image attention (6 queries x 4096 keys, 8 heads x 16; transformer.py:163-166): below 128 (batch, head)
+    blocks cor_attention runs attn_fewq_wide (one thread per (query, key slot): batch 1 is latency-bound), from 128 on attn_fewq (one thread
+    per key slot, all queries): the same slots, the same merge order -> a sample's output is bit-identical alone and inside a large batch;
+    both against torch fp32."""
+    ops, _ = _ops()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B, H, hd, Tq, Tk = 20, 8, 16, 6, 4096
+    q = torch.randn((B * Tq, H * hd), generator=g, device=DEV).to(T)
+    k = torch.randn((B * Tk, H * hd), generator=g, device=DEV).to(T)
+    v = torch.randn((B * Tk, H * hd), generator=g, device=DEV).to(T)
+    big = ops.attention(q, k, v, B, H, Tq, Tk, hd, hd ** -0.5, out_dtype=F32)                      # 160 blocks: attn_fewq
+    for b in (0, 7, 19):
+        one = ops.attention(q[b * Tq:(b + 1) * Tq].contiguous(), k[b * Tk:(b + 1) * Tk].contiguous(), v[b * Tk:(b + 1) * Tk].contiguous(),
+                            1, H, Tq, Tk, hd, hd ** -0.5, out_dtype=F32)                             # 8 blocks: attn_fewq_wide
+        assert torch.equal(one, big[b * Tq:(b + 1) * Tq]), b
+    sp = lambda t, Tn: t.float().reshape(B, Tn, H, hd).transpose(1, 2)
+    ref = (torch.softmax(sp(q, Tq) @ sp(k, Tk).transpose(2, 3) * hd ** -0.5, -1) @ sp(v, Tk)).transpose(1, 2).reshape(B * Tq, H * hd)
+    report(f"decoder_cross_attention_{T}", big, ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("tag", ["win14", "glob16"])
 def test_sam_attention_vs_reference_golden(tag):
     """qkv GEMM -> cor_sam_attention -> proj GEMM against lib/sam_model/image_encoder.py Attention (golden)."""
