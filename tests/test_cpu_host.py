@@ -227,6 +227,30 @@ def test_bench_launch_plan_and_command():
     assert not re.search(r"^(import|from)\s+(torch|cor_amd)", head, flags=re.M), "the launching parent must not import torch / cor_amd at module level"
 
 
+def test_bench_config_presets_express_every_baseline_config():
+    """bench.py --config N: every BASELINE.json config as a preset - model, batch, gallery rows and the gallery's storage
+    type (independent of --dtype); explicit flags still win; the preset table quotes BASELINE.json's strings verbatim."""
+    import json
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    for n in (1, 2, 3, 4):
+        assert bench.BASELINE_CONFIGS[n] == base[n], n
+    a = bench.parse([])
+    assert (a.sam, a.batch, a.gallery, a.gallery_dtype, a.config_text) == ("sam_base", 32, 100000, "bf16", None)   # the headline line
+    a = bench.parse(["--dtype", "f32"])
+    assert a.gallery_dtype == "f32"
+    a = bench.parse(["--config", "1"])
+    assert (a.sam, a.siglip, a.batch, a.gallery, a.gallery_dtype) == ("sam_base", "ViT-B-16-SigLIP-384", 32, 10000, "bf16")
+    a = bench.parse(["--config", "2", "--gpus", "8"])
+    assert (a.batch, a.gallery, a.gpus) == (32, 100000, 8)
+    a = bench.parse(["--config", "3"])
+    assert (a.sam, a.siglip, a.batch) == ("sam_large", "ViT-L-16-SigLIP-384", 64)
+    a = bench.parse(["--config", "4", "--gpus", "8"])
+    assert (a.sam, a.batch, a.gallery, a.gallery_dtype) == ("sam_large", 64, 1000000, "fp16") and a.config_text == base[4]
+    a = bench.parse(["--config", "4", "--gallery", "200000", "--gallery-dtype", "bf16", "--batch", "8"])               # explicit flags win
+    assert (a.batch, a.gallery, a.gallery_dtype) == (8, 200000, "bf16")
+
+
 def test_bench_gpus2_gloo_starts_two_ranks_by_itself_and_refuses_a_mismatch():
     """`python bench.py --gpus 2 --backend gloo --launch-check` with NO WORLD_SIZE: the parent starts two ranks through
     torch.distributed.run, they form a gloo group of 2 and rank 0's JSON line is relayed; a WORLD_SIZE that disagrees with
