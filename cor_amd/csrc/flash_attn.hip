@@ -578,17 +578,15 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   const unsigned vk0 = (unsigned)((srow * a.d3 + a.H * 64 + kswz) * 2), vk1 = vk0 + (unsigned)(32 * a.d3 * 2);
   const unsigned vv0 = (unsigned)((srow * a.d3 + 2 * a.H * 64 + vswz) * 2), vv1 = vv0 + (unsigned)(32 * a.d3 * 2);
   const long tile_bytes = (long)KT * a.d3 * 2;
+  // (both pieces of a tile under one M0 setting: glds16_so_pair4k, 5 instructions instead of 10 per tile and wave)
+  const unsigned vk0p = vk0 + 2048u, vk1m = vk1 - 2048u, vv0p = vv0 + 2048u, vv1m = vv1 - 2048u;
   auto issue_k = [&](int t, int slot) {
     const char* base = (const char*)kvbase + (long)min(t, nt - 1) * tile_bytes;
-    const unsigned d = lds0 + slot * TILE_B + wofs;
-    glds16_so(base, vk0, d);
-    glds16_so(base, vk1, d + 4096);
+    glds16_so_pair4k(base, vk0p, vk1m, lds0 + slot * TILE_B + wofs + 2048u);
   };
   auto issue_v = [&](int t, int slot) {
     const char* base = (const char*)kvbase + (long)min(t, nt - 1) * tile_bytes;
-    const unsigned d = lds0 + K_BYTES + slot * TILE_B + wofs;
-    glds16_so(base, vv0, d);
-    glds16_so(base, vv1, d + 4096);
+    glds16_so_pair4k(base, vv0p, vv1m, lds0 + K_BYTES + slot * TILE_B + wofs + 2048u);
   };
   // (the converted row-table fragments are pinned BEFORE the copies: hipcc waits for its own loads with vmcnt(0) when it cannot
   // count the asm copies behind them, which would drain the copies too)
