@@ -588,6 +588,11 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     const char* base = (const char*)kvbase + (long)min(t, nt - 1) * tile_bytes;
     glds16_so_pair4k(base, vv0p, vv1m, lds0 + K_BYTES + slot * TILE_B + wofs + 2048u);
   };
+  // the loop's copies: running source pointers (K(t+3), V(t+1); they stop at the last tile, which is then re-read and dropped) instead of
+  // a 64-bit multiply per copy (the loop carried 49 scalar instructions per tile for addresses)
+  const char* ksrc = (const char*)kvbase + (long)min(3, nt - 1) * tile_bytes;
+  const char* vsrc = (const char*)kvbase + (long)min(1, nt - 1) * tile_bytes;
+  const unsigned ldsK = lds0 + wofs + 2048u, ldsV = lds0 + K_BYTES + wofs + 2048u;
   // (the converted row-table fragments are pinned BEFORE the copies: hipcc waits for its own loads with vmcnt(0) when it cannot
   // count the asm copies behind them, which would drain the copies too)
 #pragma unroll
@@ -645,18 +650,23 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   }
   __syncthreads();                                      // every wave is done with K tile 0 before iteration 0 refills its slot
 
-  int c3 = 0;                                           // t % 3
   unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};      // STAMP: cycles in [DMA issue | phase A | reference update | phase B | vmcnt wait | barrier]
   // one key tile; S(t) arrives in `s`, S(t+1) leaves in `sn`
-  auto tile_step = [&](const int t, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
-    const int c3p1 = c3 == 2 ? 0 : c3 + 1, c3p2 = c3 == 0 ? 2 : c3 - 1;      // (t+1) % 3, (t+2) % 3 = (t-1) % 3
+  // C3 = t % 3 and TAIL (the source pointers may have to stop at the last tile) are compile-time: six tiles per loop trip make every ring
+  // offset an immediate (the loop carried ~10 scalar instructions per tile for t % 3 and 6 vector adds for the fragment addresses)
+  auto tile_step = [&](auto C3_, auto TAIL_, const int t, f32x16 (&s)[2], f32x16 (&sn)[2]) __attribute__((always_inline)) {
+    constexpr int c3 = decltype(C3_)::value;
+    constexpr bool TAIL = decltype(TAIL_)::value;
+    constexpr int c3p1 = c3 == 2 ? 0 : c3 + 1, c3p2 = c3 == 0 ? 2 : c3 - 1;  // (t+1) % 3, (t+2) % 3 = (t-1) % 3
     unsigned long long ts[8];
     auto stamp = [&](int i) { if (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } };
     stamp(0);
     // (the slots are free from the top of the iteration: K(t) and V(t-2) were last read in iteration t-1; issuing the four copies
     // after phase A, after phase B or split between them instead measured +-0.5 %)
-    issue_k(t + 3, c3);                                 // over K(t), last read in iteration t-1
-    issue_v(t + 1, c3p1);                               // over V(t-2), last read in iteration t-1
+    glds16_so_pair4k(ksrc, vk0p, vk1m, ldsK + c3 * TILE_B);       // K(t+3) over K(t), last read in iteration t-1
+    glds16_so_pair4k(vsrc, vv0p, vv1m, ldsV + c3p1 * TILE_B);    // V(t+1) over V(t-2), last read in iteration t-1
+    if (!TAIL || t + 4 < nt) ksrc += tile_bytes;
+    if (!TAIL || t + 2 < nt) vsrc += tile_bytes;
     stamp(1);
     const char* Vs = Vring + c3p2 * TILE_B;             // V(t-1)
     const char* Ks = Kring + c3p1 * TILE_B;             // K(t+1)
@@ -673,11 +683,16 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       vf[i] = make_uint4(u0.x, u0.y, u1.x, u1.y);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    // (round 5, measured and not kept: with the bias fma gone phase A has ~25 vector instructions for 8 MFMAs and phase B ~100 for 8;
+    // moving the PV MFMAs of the second key block to phase B - 4 + 12, O^T rescaled at the end of the iteration - took 1.941 ms against
+    // 1.925: between the two waves of a SIMD such moves are zero-sum. NPA = 4 selects that form.)
+    constexpr int NPA = 8;
+    auto pv = [&](int i) __attribute__((always_inline)) {
       const int kb = i >> 2, ks = (i >> 1) & 1, db = i & 1;
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i]), __builtin_bit_cast(bf16x8, pf[kb][ks]), o[db], 0, 0, 0);
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) pv(i);
     float mloc;
     {
 #pragma unroll
@@ -696,25 +711,29 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
         }
       mloc = fmaxf(max3f_(m4[0], m4[1], m4[2]), m4[3]);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {                    // 1 MFMA : 4 VALU (CB: 2)
+      for (int i = 0; i < (NPA == 4 ? 4 : 12); ++i) {   // 1 MFMA : 4 VALU (CB: 2)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, CB ? 2 : 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NPA == 4 ? 6 : (CB ? 2 : 4), 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     stamp(2);
-    float msub = 0.f;
+    float msub = 0.f, alpha = 1.f;
+    bool resc;
     {
       mloc = fmaxf(mloc, other_half(mloc)) + rh;        // true tile max (x + rh)
-      if (__builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0) {     // lazy rescale (see the header)
+      resc = __builtin_amdgcn_ballot_w64(mloc > m + 8.0f) != 0;     // lazy rescale (see the header)
+      if (resc) {
         const float mnew = fmaxf(m, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        alpha = __builtin_amdgcn_exp2f(m - mnew);
         m = mnew;
         lsum[0] *= alpha; lsum[1] *= alpha; lsum[2] *= alpha;
+        if (NPA == 8) {
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+          for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+        }
       }
       msub = m - rh;                                    // p = 2^(x + rh - m)
     }
@@ -723,16 +742,27 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
     uint4 kf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) kf[i] = *(const uint4*)(Ks + (i >> 2) * 32 * 128 + kch[i & 3]);
+    if (!CB) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sn[kb][e] = CB ? wreg[kb][e] : 0.f;
+        for (int e = 0; e < 16; ++e) sn[kb][e] = 0.f;
+    }
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = NPA; i < 8; ++i) pv(i);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), sn[kb], 0, 0, 0);
+      for (int c = 0; c < 4; ++c) {
+        if (CB && c == 0) {
+          // the chain's first MFMA takes the column bias as its C operand and writes a DIFFERENT register block: hipcc's builtin ties C to D
+          // and copied the 32 start values per tile (34 v_mov in the phase); in asm D and C are separate operands. The next MFMA of the
+          // chain reads D as its C (same block, same opcode: issues back to back, as the compiler's own chains do).
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sn[kb]) : "v"(__builtin_bit_cast(u32x4, kf[kb * 4])), "v"(__builtin_bit_cast(u32x4, qf[0])), "v"(wreg[kb]));
+        } else
+          sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kb * 4 + c]), __builtin_bit_cast(bf16x8, qf[c]), sn[kb], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -746,12 +776,20 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
       lsum[1] = sum2_bf16(pf[kb][1].y, sum2_bf16(pf[kb][1].x, lsum[1])); lsum[2] = sum2_bf16(pf[kb][1].w, sum2_bf16(pf[kb][1].z, lsum[2]));
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {         // 1 MFMA : 12 VALU (32 sub + 32 exp2 + 16 cvt_pk + 16 dot2)
+    for (int i = 0; i < (NPA == 4 ? 10 : (CB ? 6 : 8)); ++i) {   // 1 MFMA : 12 VALU (32 sub + 32 exp2 + 16 cvt_pk + 16 dot2); CB: two of the eight score MFMAs are asm
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NPA == 4 ? 10 : (CB ? 16 : 12), 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    c3 = c3p1;
+    if (NPA < 8) {
+      asm volatile("" :: "v"(lsum[1]), "v"(lsum[2]));   // (keeps the pure softmax arithmetic above the branch: LLVM sinks it otherwise)
+      if (resc) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+      }
+    }
     stamp(4);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K(t+2), V(t) (issued one iteration ago) have landed; this iteration's 4 stay in flight
     stamp(5);
@@ -764,10 +802,26 @@ __global__ void __launch_bounds__(256, 2) flash_global_pipe(const FlashArgs a) {
   };
   f32x16 s2[2];
   {
+    // six tiles per trip: t % 3 (ring slots) and t % 2 (which of the two score register sets holds S(t): the copy S <- S(t+1) at the
+    // end of every tile was 32 v_mov per tile and wave) are compile-time. The trips cover the tiles whose copies need no clamping (every
+    // tile of a trip has K(t+4) to advance to); the tail runs the same sequence one tile at a time with the clamps.
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    int t = 0;
 #pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-      tile_step(t, s, s2);
-      s[0] = s2[0]; s[1] = s2[1];
+    for (; t + 9 < nt; t += 6) {                        // tiles t .. t+5 with t + 5 + 4 < nt: no clamp
+      tile_step(I0{}, std::false_type{}, t, s, s2);     tile_step(I1{}, std::false_type{}, t + 1, s2, s);
+      tile_step(I2{}, std::false_type{}, t + 2, s, s2); tile_step(I0{}, std::false_type{}, t + 3, s2, s);
+      tile_step(I1{}, std::false_type{}, t + 4, s, s2); tile_step(I2{}, std::false_type{}, t + 5, s2, s);
+    }
+    // tail (up to 11 tiles, one at a time, t % 6 == 0 at its start): the same sequence with the clamps
+#pragma unroll 1
+    for (; t < nt; t += 6) {
+      if (t < nt) tile_step(I0{}, std::true_type{}, t, s, s2);
+      if (t + 1 < nt) tile_step(I1{}, std::true_type{}, t + 1, s2, s);
+      if (t + 2 < nt) tile_step(I2{}, std::true_type{}, t + 2, s, s2);
+      if (t + 3 < nt) tile_step(I0{}, std::true_type{}, t + 3, s2, s);
+      if (t + 4 < nt) tile_step(I1{}, std::true_type{}, t + 4, s, s2);
+      if (t + 5 < nt) tile_step(I2{}, std::true_type{}, t + 5, s2, s);
     }
   }
   // PV(nt-1) and its row sums
