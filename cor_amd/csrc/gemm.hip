@@ -43,6 +43,7 @@ struct GemmArgs {
   const float* bias; const float* col_scale; const float* residual;
   long ldr; int res_row_mod; int act;
   int group_m;         // tile order: M-panels per band (L2 blocking)
+  unsigned long long* stamps;   // COR_PROBES: cycle stamps of block 0 / thread 0, 16 per tile (tools/dbg/gemm_stamps.py)
   int dbg;             // timing-only ablation knobs (tools/gemm_ksweep.py): 1 no C stores, 2 no epilogue, 4 no MFMA
   int vec_epi;         // 1: N, ldc, ldr multiples of 4 and all epilogue pointers 16-B aligned (host-checked)
   int rev;             // 1: walk the tile order backwards (COR_ORDER_REVERSE: start where the producer of A finished)
@@ -365,11 +366,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 }
 template <typename TO, int MI, int NJ, int ACT, bool HAS_RES, bool NT, typename FILL, typename PRE, typename BCOL>
 __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, PRE&& pre, BCOL&& bias_col, float* stg, const GemmArgs& g, __amdgpu_buffer_rsrc_t crs,
-                                                int mbase, int nbase, int lane) {
+                                                int mbase, int nbase, int lane, int g_tile_ix = 0) {
   constexpr int VW = sizeof(TO) == 2 ? 8 : 4;
   constexpr int CV = 32 / VW, RPP = 64 / CV, PASS = 32 / RPP, Q4 = VW / 4;   // bf16: 4 lanes/row, 16 rows/pass, 2 passes
   constexpr bool HEAVY_ACT = ACT != COR_ACT_NONE && ACT != COR_ACT_RELU;             // exp + rcp temporaries: depth 2 spills 5-6 registers there
   constexpr int NB = MI * NJ, D = (HAS_RES && sizeof(TO) == 4 && !HEAVY_ACT) ? 2 : 1;   // residual prefetch depth (deeper, or 2 with bf16 C: spills)
+#ifdef COR_PROBES
+  int sti_ = 3;
+#define EPI_STAMP() do { if (g.stamps && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); g.stamps[g_tile_ix * 16 + sti_++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define EPI_STAMP() do { } while (0)
+#endif
   const int cv = lane % CV, row0 = lane / CV;
   // Residual loads run D blocks ahead of their use (the K-loop fragment registers are free here): one block at a time, each
   // block waited for its own HBM round trip and - VMEM retiring in order - for the previous block's stores, eight times per
@@ -385,7 +392,7 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, PRE&& pre, BCOL&& b
 #pragma unroll
       for (int q4 = 0; q4 < Q4; ++q4) {
         const f32x4* rp = (const f32x4*)(g.residual + (long)rr * g.ldr + min(n + 4 * q4, g.N - 4));
-        r[ps][q4] = COR_DBG(g, 0x8000) ? __builtin_nontemporal_load(rp) : *rp;           // probe: non-temporal residual loads
+        r[ps][q4] = COR_DBG(g, 0x8000) ? f32x4{1.f, 2.f, 3.f, 4.f} : *rp;                 // probe: no residual loads
       }
     }
   };
@@ -408,7 +415,9 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, PRE&& pre, BCOL&& b
   for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+v"(bcol[nj][jb]));   // hipcc places the bias wait HERE (nothing younger but the residual prefetch)
+  EPI_STAMP();                                        // 3: first residual loads issued, bias landed
   pre();                                              // next tile: operand offsets + prologue LDS-DMAs (not tracked by hipcc)
+  EPI_STAMP();                                        // 4: next tile's prologue issued
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int mi = blk / NJ, nj = blk % NJ;
@@ -436,11 +445,13 @@ __device__ __forceinline__ void epilogue_buf_ct(FILL&& fill, PRE&& pre, BCOL&& b
         u[0] = __float_as_uint(v[0][0]); u[1] = __float_as_uint(v[0][1]); u[2] = __float_as_uint(v[0][2]); u[3] = __float_as_uint(v[0][3]);
       }
       // NT (compile-time: a runtime choice of the cache-policy immediate was three branches per store): non-temporal C stores, see launch_gemm
-      if constexpr (NT) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);
+      if (COR_DBG(g, 0x200000)) { if (u[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0); }   // probe: (almost) no C stores
+      else if constexpr (NT) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);
       else if (COR_DBG(g, 0x2000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 2);        // probes: nt / sc1 on any output
       else if (COR_DBG(g, 0x4000)) __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 16);
       else __builtin_amdgcn_raw_buffer_store_b128(u, crs, off, 0, 0);
     }
+    EPI_STAMP();                                      // 5 + blk: block written
     if constexpr (HAS_RES) {
       if (blk + D < NB) load_res(blk + D, res[blk % D]);
     }
@@ -650,6 +661,12 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
 
+#ifdef COR_PROBES
+#define PP_STAMP(i_) do { if (g.stamps && blockIdx.x == 0 && tid == 0) { __builtin_amdgcn_sched_barrier(0); g.stamps[qi * 16 + (i_)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define PP_STAMP(i_) do { } while (0)
+#endif
+    PP_STAMP(0);
     // B(0), A(0) landed: younger = A(1), B(1) (8 LDS-DMA) and the previous tile's buffer stores
     if (stores_pending) {
       if constexpr (NSTORE == 16) { if (nkt > 1) COR_VMCNT(24); else COR_VMCNT(16); }
@@ -754,7 +771,9 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
       COR_BAR();
       a3 = a3 == 2 ? 0 : a3 + 1;
     }
+    PP_STAMP(1);
     if (wr == 0) COR_BAR();                          // realign the two wave rows; the ring is idle from here
+    PP_STAMP(2);
 
     const int cm0 = m0, cn0 = n0;
     const int Ln = tile_of(++qi);
@@ -787,7 +806,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
       if (g.nt_c) epilogue_ct16<MI, NJ, A_, true>(accv, pre, (char*)stg, g, crs, mb, nb, lane);                \
       else epilogue_ct16<MI, NJ, A_, false>(accv, pre, (char*)stg, g, crs, mb, nb, lane);                      \
     } else                                                                                                      \
-    if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane);          \
+    if (g.residual) epilogue_buf_ct<TO, MI, NJ, A_, true, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane, qi - 1);  \
     else if (sizeof(TO) == 2 && g.nt_c) epilogue_buf_ct<TO, MI, NJ, A_, false, sizeof(TO) == 2>(fill, pre, bias_col, stg, g, crs, mb, nb, lane); \
     else epilogue_buf_ct<TO, MI, NJ, A_, false, false>(fill, pre, bias_col, stg, g, crs, mb, nb, lane);
     if (COR_DBG(g, 2)) {                             // timing ablation: one element per lane instead of the epilogue
@@ -814,6 +833,9 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
       default: COR_EPI(COR_ACT_NONE) break;
     }
 #undef COR_EPI
+#ifdef COR_PROBES
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[(qi - 1) * 16 + 15] = __builtin_readcyclecounter();
+#endif
     if (Ln < 0) break;
     L = Ln;
     stores_pending = !COR_DBG(g, 2);
@@ -890,8 +912,12 @@ int launch_gemm(const void* A, long lda, const void* W, long ldw, void* C, long 
   g.A = (const char*)A; g.W = (const char*)W; g.C = (char*)C;
   g.lda_b = lda * esz; g.ldw_b = ldw * esz; g.ldc = ldc;
   g.M = M; g.N = N; g.Kb = (int)(K * esz);
+  g.stamps = nullptr;
+#ifdef COR_PROBES
+  if (g_gemm_dbg & 0x100000) { g.stamps = (unsigned long long*)col_scale; col_scale = nullptr; }   // probe: col_scale carries the stamp buffer
+#endif
   g.bias = bias; g.col_scale = col_scale; g.residual = residual; g.ldr = ldr; g.res_row_mod = res_row_mod; g.act = act;
-  g.dbg = g_gemm_dbg & 0xefff; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
+  g.dbg = g_gemm_dbg & 0x3fefff; g.rev = (cfg_arg & COR_ORDER_REVERSE) ? 1 : 0;
   g.order = 1;                                       // resolved below (persistent kernel only): see set_tile
   // bf16 outputs of the persistent kernel are stored non-temporally: with the whole-line epilogue every store instruction writes
   // complete 128-byte lines, nothing is left for a cache to merge, and as plain stores the C stream evicts the A / W panels the K

@@ -36,17 +36,24 @@ SHAPES = [  # (M, N, K, act, residual, out_f32, label)
 
 def enc(c):
     """command-line cfg -> per-call cfg: kernel = c % 100, tile-order group = c // 100 (ablation bits 8.. of cfg)."""
+    if isinstance(c, str) and ":" in c:                 # "13:0x4000": kernel 13 with development bits 0x4000 of the ablation field (probe build)
+        k, d = c.split(":")
+        return int(k) | (int(d, 0) << 8)
+    c = int(c)
     return (c % 100) | ((16 * (c // 100)) << 8)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfgs", type=int, nargs="*", default=[1, 2, 3, 4, 9, 13])
+    ap.add_argument("--cfgs", nargs="*", default=["1", "2", "3", "4", "9", "13"])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="", help="label substring filter")
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    if any(c >= 100 or (c % 100) not in (0, 1, 2, 3, 4, 9, 13) for c in a.cfgs):
+    global SHAPES
+    if a.only: SHAPES = [x for x in SHAPES if a.only in x[6]]
+    if any(":" in c or int(c) >= 100 or (int(c) % 100) not in (0, 1, 2, 3, 4, 9, 13) for c in a.cfgs):
         _native.use_probe_library()                     # the production ABI answers COR_EINVAL to these (ADVICE r3)
         print("# experimental selectors requested: bound tools/probes/libcor_probes.so", file=sys.stderr)
     lib = _native.load()
@@ -78,7 +85,7 @@ def main():
                 times[c].append(e0.elapsed_time(e1))
         fl = 2.0 * M * N * K
         row = dict(shape=f"{M}x{N}x{K}", label=label, err_vs_torch=err_ref,
-                   **{f"cfg{c}": dict(tf_med=fl / (sorted(times[c])[len(times[c]) // 2] * 1e-3) / 1e12,
+                   **{f"cfg{c}": dict(us_med=1e3 * sorted(times[c])[len(times[c]) // 2], tf_med=fl / (sorted(times[c])[len(times[c]) // 2] * 1e-3) / 1e12,
                                       tf_best=fl / (min(times[c]) * 1e-3) / 1e12, diff_vs_first=errs[c]) for c in a.cfgs})
         print(json.dumps(row), flush=True)
         res.append(row)
