@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 constexpr float SIM_DELTA = 6.4e-5f * 1.01f;
 constexpr int FS_MAX = 8192;                           // candidates per query held in LDS by sim_final (64 KiB)
 constexpr int SL_MAX = 512;                            // short list (re-scored exactly)
-constexpr int SCAN_NS = 4, SCAN_AHEAD = 3;             // LDS-DMA ring of 32-KiB gallery super-tiles (64 rows): 128 KiB, one block per CU
+constexpr int SCAN_NS = 5, SCAN_AHEAD = 4;             // LDS-DMA ring of 32-KiB gallery super-tiles (64 rows): 160 KiB = all of LDS, one block per CU
 
 struct ScanArgs {
   int Bq, Ng, nqg, nsplit, tiles_per_split;
@@ -328,6 +328,8 @@ struct ScanArgs {
                                    // SAMPLE: atomic max of the group (slice, lane half) maximum into super-group (split * 2 + h) & 31; APPEND: read
   const float* dq; int k;          // APPEND: delta_q (sim_prep) and k: tau_q = k-th largest super-group maximum - delta_q, computed in the prologue
   float tau_add;                   // 0; timing-only ablation (COR_TOPK_DEBUG_NOCAND): +1e30 = no candidate ever passes
+  int probe_same;                  // COR_PROBES (timing only): every block streams the same 8 super-tiles (cache-resident gallery)
+  unsigned long long* stamps;      // COR_PROBES: cycle stamps of waves 0 and 4 of block 0 (tools/sim_stamps.py scan)
   float* tau; int* cnt; float* rec_s; int* rec_g; int cap;           // APPEND: tau_q (written by the blocks of slice 0 for the selection kernel); record i of stream (q, slice, half): 16 scores + first row
 };
 
@@ -364,11 +366,48 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
   // double buffering is needed.
   const bool late = wave >= 4;
 
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  // A super-tile = 64 rows x 512 B; wave w copies rows 8w .. 8w+7 with FOUR LDS-DMA instructions of two rows each under ONE M0 setting: the
+  // instruction offsets 0 / 1024 / 2048 / 3072 move the LDS and the global address alike (rows are contiguous in both), the per-lane
+  // offset carries the row of the pair and the swizzled chunk. (Round 5 stamps: per-lane 64-bit addresses + an M0 save / set / restore per
+  // instruction cost a wave 520-630 cycles per super-tile, both waves of a SIMD at the same time.)
+  const unsigned wbase = (unsigned)wave * 4096u;       // this wave's first row (bytes) in a ring slot
+  const int st_e = lane >> 5, st_sl = lane & 31;
+  unsigned st_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)(st_e * 512 + ((st_sl ^ ((8 * wave + 2 * i + st_e) & 15)) << 4));
+  const int t0 = split * a.tiles_per_split, t1 = min(t0 + a.tiles_per_split, a.ntiles);     // super-tiles of 64 rows
+  auto issue = [&](int t) {
+#ifdef COR_PROBES
+    const long g0 = (long)((a.probe_same & 1) ? (t & 7) : t) * a.tile_stride * 64;
+#else
+    const long g0 = (long)t * a.tile_stride * 64;
+#endif
+    const unsigned dst = lds0 + ((t - t0) % NS) * STILE + wbase;
+    if (g0 + 64 <= a.Ng) {                             // (scalar) every row of the super-tile is inside the shard
+      const char* sb = (const char*)G + (g0 + 8 * wave) * 512;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(st_off[0]), "v"(st_off[1]), "v"(st_off[2]), "v"(st_off[3]), "s"(sb), "s"(dst) : "memory");
+    } else {                                           // the shard's last super-tile: clamped duplicates (masked to -inf in the epilogue)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * wave + 2 * i + st_e;
+        glds16(G + min(g0 + row, (long)a.Ng - 1) * C + ((st_sl ^ (row & 15)) << 3), dst + 1024 * i);
+      }
+    }
+  };
+  // The ring is filled FIRST: the HBM round trip of the first super-tiles runs under the prologue below (threshold network, 32 KiB of
+  // K-fragments per wave); tau_s sits in the slot these copies do not touch.
+  for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
+
   // APPEND: tau_q in the prologue (round 4: no sim_tau launch). Thread <-> query of this block: its 32 super-group maxima, a 32-element
   // bitonic network in registers (the K-fragments are not loaded yet), tau_q = k-th largest - delta_q (fewer than k non-empty super-groups:
   // -inf, every row is a candidate). Any lower bound of the k-th best score is valid, so 32 unions of the (slice, lane half) groups serve
   // as well as the 512 groups the launch ranked (~15 % more candidates).
-  __shared__ float tau_s[256 * QB];
+  float* tau_s = (float*)(smem + (SCAN_NS - 1) * 2 * 32 * 256 * 2);   // in the LAST ring slot: first written by the copies behind the loop's first barrier
   if (!SAMPLE) {
     const int ql = tid;                                // 256 * QB queries per block, 512 threads
     if (ql < 256 * QB) {
@@ -413,27 +452,11 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     tau[qb] = SAMPLE ? 0.f : tau_s[wave * (32 * QB) + qb * 32 + r] + a.tau_add;
     gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
-  const unsigned wbase = (unsigned)wave * 1024u;       // this wave's first slot (bytes) per 8-KiB pass
-  int st_row[4], st_src[4];                            // a super-tile = 64 rows x 512 B = four 8-KiB passes of the block
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 512 * i, row = c >> 5, sl = c & 31;
-    st_row[i] = row; st_src[i] = (sl ^ (row & 15)) * 8;
-  }
   // read address of K-step c: row r, chunk (2c + h) ^ (r & 15) = ((c ^ (r>>1 & 7)) << 1) | ((h ^ r) & 1): one XOR per read instead
   // of 16 address registers
   const int rd_base = r * 512 + (((h ^ r) & 1) << 4), rd_x = (r >> 1) & 7;
 #define SIM_RD(c_) (rd_base + ((((c_) ^ rd_x)) << 5))
 
-  const int t0 = split * a.tiles_per_split, t1 = min(t0 + a.tiles_per_split, a.ntiles);     // super-tiles of 64 rows
-  auto issue = [&](int t) {
-    const long g0 = (long)t * a.tile_stride * 64;
-    const unsigned dst = lds0 + ((t - t0) % NS) * STILE + wbase;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      glds16(G + min(g0 + st_row[i], (long)a.Ng - 1) * C + st_src[i], dst + 512 * 16 * i);
-  };
   f32x16 acc[QB];
   // epilogue of one 32-row tile (rows g0 ..): SAMPLE keeps the group maximum; APPEND compares the tile maximum with tau and
   // appends the rare scores >= tau to the lane's private stream list
@@ -474,10 +497,9 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     }
   };
   auto mfma_tile = [&](const char* buf) {
+    f32x16 zero;                                       // C operand of the first K-step: the inline constant 0 (no 32 v_mov per tile)
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[qb][e] = 0.f;
+    for (int e = 0; e < 16; ++e) zero[e] = 0.f;
     uint4 af[4];                                       // A fragments four K-steps ahead of the MFMAs that consume them
 #pragma unroll
     for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + SIM_RD(c));
@@ -488,35 +510,59 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         if (__is_same(TG, bf16_t))
-          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][c]), acc[qb], 0, 0, 0);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][c]), c == 0 ? zero : acc[qb], 0, 0, 0);
         else
-          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][c]), acc[qb], 0, 0, 0);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][c]), c == 0 ? zero : acc[qb], 0, 0, 0);
       }
     }
   };
 
-  for (int t = t0; t < min(t0 + AHEAD, t1); ++t) issue(t);
   // (s_setprio 1 for the younger half - waves 4-7 - before the loop, the guide's static-priority item, and a sample stride of 32 instead of 16
   // at 1M rows: no difference in a same-box A/B - 320-333 us for all three builds on a box where this clock-bound kernel runs 20 % slower than
   // on the round's other boxes, 268-272; a first cross-box comparison had read the box as the change. Not kept.)
   int g_pending = -1;                                  // late waves: tile whose epilogue is still owed
+#ifdef COR_PROBES
+#define SC_STAMP(i_) do { if (!SAMPLE && a.stamps && blockIdx.x == 0 && (tid & 255) == 0 && t - t0 < 24) { __builtin_amdgcn_sched_barrier(0); \
+    a.stamps[((tid >> 8) * 24 + (t - t0)) * 8 + (i_)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SC_STAMP(i_) do { } while (0)
+#endif
   for (int t = t0; t < t1; ++t) {
     // super-tile t has landed once at most 4 * (super-tiles issued after t) of this wave's DMA are still outstanding (VMEM
     // retires in order; candidate stores issued in between only make the wait stricter)
+    // Round 5 (cycle stamps, tools/sim_stamps.py): VMEM retires in order, so the ~5 candidate stores of a record appended in the last period
+    // count among "the 4 (AHEAD - 1) youngest operations" and the wait below then also waits for copies issued one period ago (500-1 000
+    // cycles per super-tile with a ring of 4). A ring of FIVE (all 160 KiB of LDS; tau_s lives in the last slot until the first barrier) puts
+    // one more period between a copy's issue and the wait that can be forced onto it.
     const int later = min(t1 - 1 - t, AHEAD - 1);
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SC_STAMP(0);
     __builtin_amdgcn_s_barrier();                      // every wave's part of super-tile t is in LDS; t-1 is fully consumed
+    SC_STAMP(1);
     if (t + AHEAD < t1) issue(t + AHEAD);              // -> ring slot of super-tile t-1
+#ifdef COR_PROBES
+    if (a.probe_same & 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // probe: how deep is the backlog? (everything but the newest super-tile)
+    if (a.probe_same & 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+    SC_STAMP(2);
     const char* buf = smem + ((t - t0) % NS) * STILE;
     const int g0 = t * a.tile_stride * 64;
     if (active) {
       if (late && g_pending >= 0) epilogue(g_pending);
+      SC_STAMP(3);
+      if (late) __builtin_amdgcn_s_setprio(2);
       mfma_tile(buf);
+      if (late) __builtin_amdgcn_s_setprio(0);
+      SC_STAMP(4);
       epilogue(g0);
+      SC_STAMP(5);
       mfma_tile(buf + TILE);
+      SC_STAMP(6);
       if (late) g_pending = g0 + 32; else epilogue(g0 + 32);
+      SC_STAMP(7);
     }
   }
   if (active && late && g_pending >= 0) epilogue(g_pending);
@@ -1512,6 +1558,10 @@ int launch_v3(const float* Q, const TG* G, int Bq, int Ng, int k, long long g_of
   a.nsplit = p.nsplit; a.tiles_per_split = p.tiles_per_split; a.ntiles = p.tiles; a.tile_stride = 1;
   a.dq = dq; a.k = k;
   a.tau = tau; a.cnt = cnt; a.rec_s = rec_s; a.rec_g = rec_g; a.cap = p.cap; a.tau_add = (flags & 4) ? 1e30f : 0.f;
+#ifdef COR_PROBES
+  a.stamps = (flags & 32) ? (unsigned long long*)(w + cor_topk_workspace_bytes(Bq, Ng, k)) : nullptr;   // tools/sim_stamps.py: 2 MiB behind the workspace
+  a.probe_same = ((flags & 64) ? 1 : 0) | ((flags & 128) ? 2 : 0) | ((flags & 256) ? 4 : 0);
+#endif
   hipLaunchKernelGGL((sim_scan<TG, QB, false>), dim3(p.nqg * p.nsplit), dim3(512), lds, s, G, a);
   COR_CHECK_LAUNCH();
   // D. exact selection: one 256-thread block per query. (COR_TOPK_WAVE_FINAL: the one-wave-per-query kernel of the small-shard path fed
