@@ -10,16 +10,18 @@ from cor_amd import ops, _native
 _native.use_probe_library()
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (131072, 768, 768)
 extra = int(sys.argv[4], 16) if len(sys.argv) > 4 else 0
+mode = sys.argv[5] if len(sys.argv) > 5 else "res"          # res: fp32 out + residual | bf16: bf16 out, bias | gelu: bf16 out, bias + GELU
 dev = "cuda:0"
 A = torch.randn((M, K), device=dev).bfloat16(); W = (torch.randn((N, K), device=dev) / K ** 0.5).bfloat16()
 bias = torch.randn((N,), device=dev); R = torch.randn((M, N), device=dev)
-st = torch.zeros((max(N, 1024),), device=dev, dtype=torch.float32)
+st = torch.zeros((max(N, 1024),), device=dev, dtype=torch.float32)   # 16 stamps x 8 bytes x (N / 32) tiles
 cfg = 13 | ((0x100000 | extra) << 8)
 for _ in range(3):
     st.zero_()
-    ops.gemm(A, W, out_dtype=torch.float32, bias=bias, residual=R, col_scale=st[:N], cfg=cfg)
+    if mode == "res": ops.gemm(A, W, out_dtype=torch.float32, bias=bias, residual=R, col_scale=st[:N], cfg=cfg)
+    else: ops.gemm(A, W, out_dtype=torch.bfloat16, bias=bias, act=1 if mode == "gelu" else 0, col_scale=st[:N], cfg=cfg)
 torch.cuda.synchronize()
-t = st.view(torch.int64)[:16 * 8].cpu().view(-1, 16)
+t = st.view(torch.int64)[:16 * 32].cpu().view(-1, 16)
 names = ["start", "kloop", "realign", "bias", "pre"] + [f"blk{i}" for i in range(8)] + ["", "", "end"]
 for ti in range(t.shape[0]):
     row = t[ti].tolist()
