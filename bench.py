@@ -297,9 +297,6 @@ def main():
         raise SystemExit(spawn_ranks(detail, sys.argv[1:]))
     if args.launch_check:
         return launch_check(args)
-    # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). With two forwards in flight the slots' streams and their
-    # graph branches SHARE queues, which staggers the two forwards (one's encoder beside the other's tail); with 8 or 16 queues they run in
-    # lockstep and a step takes 46.3 instead of 42.6 ms (profiles/r04_pipeline_ab.jsonl, ab10): the measured configuration is pinned.
     # HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default). With two forwards in flight the slots' streams share
     # queues, which staggers the forwards; with 8 or 16 queues a step is 1.6-2.2 % slower (profiles/r05_pipeline_queues.jsonl; the explicit
     # event-ordered form, --stagger 1, does not remove that). The measured configuration is the runtime's default, pinned here; --hw-queues N
