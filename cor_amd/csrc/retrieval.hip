@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 // v3 (16-bit galleries, C = 256, every shard size): threshold-and-append with EXACT re-scoring.
 // Per-lane sorted lists cost one divergent insertion bubble (~500 wave cycles) per accepted score, and a stream of n scores
 // accepts ~k ln(n/k) of them per lane: measured 9x the MFMA time. Instead, four launches (sim_prep + these three):
-//   A. sim_scan<SAMPLE>: MFMA scores of a strided SAMPLE of 32-row tiles; every (gallery slice, lane half) group keeps only
+//   A. sim_scan<SAMPLE>: MFMA scores of a strided SAMPLE of 32-row tiles; every (gallery slice, lane quarter) group keeps only
 //      its MAXIMUM per query and folds it (atomic max on order-preserving keys) into one of 32 SUPER-GROUPS per query. The
 //      super-groups are disjoint row sets, so the k-th largest of their maxima is a LOWER bound of the query's k-th best score over
 //      the whole shard (no dense score matrix, no selection pass).
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 //      network in registers). Rounds 2-3 ranked all 512 group maxima in a launch of their own (sim_tau, 5-7 us, launch-bound); the
 //      32 unions admit ~15 % more candidates and cost the prologue ~3 us: one launch fewer, 0-2 % faster in a same-box A/B.
 //   C. sim_scan<APPEND>: MFMA scores of the WHOLE shard; a lane compares its tile maximum with tau_q and appends the rare
-//      scores >= tau_q to the private list of its (query, gallery slice, lane half) stream (register counter, no atomics).
+//      scores >= tau_q to the private list of its (query, gallery slice, lane quarter) stream (register counter, no atomics).
 //   D. sim_final: per query, the candidates are compacted into LDS, the k-th best MFMA score T is found by a 4-pass radix
 //      select, the SHORT LIST (MFMA score >= T - delta_q, ~k entries) is RE-SCORED with the exact fp32 fmaf chain of
 //      oracle/c/sim_chain.c over the stored 16-bit values (the query rounded to the gallery dtype), and ranked by
@@ -325,12 +325,12 @@ struct ScanArgs {
   int tile_stride;                 // super-tiles between consecutive walked super-tiles (SAMPLE: >= 1; APPEND: 1)
   const uint4* qimg;               // queries rounded to the gallery dtype, fragment-major (sim_prep)
   unsigned* sg; int Bqp;           // 32 SUPER-GROUP maxima per query as order-preserving keys, sg[g * Bqp + q] (zeroed by sim_prep; 0 = empty):
-                                   // SAMPLE: atomic max of the group (slice, lane half) maximum into super-group (split * 2 + h) & 31; APPEND: read
+                                   // SAMPLE: atomic max of the group (slice, lane quarter) maximum into super-group (split * 4 + rq) & 31; APPEND: read
   const float* dq; int k;          // APPEND: delta_q (sim_prep) and k: tau_q = k-th largest super-group maximum - delta_q, computed in the prologue
   float tau_add;                   // 0; timing-only ablation (COR_TOPK_DEBUG_NOCAND): +1e30 = no candidate ever passes
   int probe_same;                  // COR_PROBES (timing only): every block streams the same 8 super-tiles (cache-resident gallery)
   unsigned long long* stamps;      // COR_PROBES: cycle stamps of waves 0 and 4 of block 0 (tools/sim_stamps.py scan)
-  float* tau; int* cnt; float* rec_s; int* rec_g; int cap;           // APPEND: tau_q (written by the blocks of slice 0 for the selection kernel); record i of stream (q, slice, half): 16 scores + first row
+  float* tau; int* cnt; float* rec_s; int* rec_g; int cap;           // APPEND: tau_q (written by the blocks of slice 0 for the selection kernel); record i of stream (q, slice, lane quarter): 8 scores + first row
 };
 
 // One block = 8 waves = 256 * QB queries (wave w owns queries q0 + 32 * QB * w ..): with QB = 2 all 512 queries of an
@@ -355,7 +355,13 @@ template <typename TG, int QB, bool SAMPLE>
 __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = 256, TILE = 32 * C * 2, STILE = 2 * TILE, NS = SCAN_NS, AHEAD = SCAN_AHEAD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  // Round 5: v_mfma_f32_16x16x32 instead of 32x32x16. A wave's 32 rows x 32 QB queries are 2 x NQ blocks of 16 x 16 = 2 NQ INDEPENDENT
+  // accumulators of four registers (the 32 x 32 form had QB = 2 dependent chains: a wave alone issued an MFMA every ~43 cycles instead of 32),
+  // and the chip holds a higher clock on this shape (MI355X guide, DVFS item 7): 512 x 1M 280-300 -> 185-200 us in the timing probe. Operand
+  // lane (n16 = lane & 15: gallery row of a 16-row block / query of a 16-query block, rq = lane >> 4: K quarter of a 32-deep step);
+  // accumulator lane: query n16, rows 4 rq + e of the row block. Same LDS image, same number of ds_read_b128, same register count.
+  constexpr int NQ = 2 * QB;                           // 16-query blocks per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n16 = lane & 15, rq = lane >> 4;
   const int qg = blockIdx.x % a.nqg, split = blockIdx.x / a.nqg;
   const int q0 = qg * (256 * QB) + wave * (32 * QB);
   const bool active = q0 < a.Bq;                     // wave-uniform: idle waves still stage and barrier
@@ -405,7 +411,7 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
 
   // APPEND: tau_q in the prologue (round 4: no sim_tau launch). Thread <-> query of this block: its 32 super-group maxima, a 32-element
   // bitonic network in registers (the K-fragments are not loaded yet), tau_q = k-th largest - delta_q (fewer than k non-empty super-groups:
-  // -inf, every row is a candidate). Any lower bound of the k-th best score is valid, so 32 unions of the (slice, lane half) groups serve
+  // -inf, every row is a candidate). Any lower bound of the k-th best score is valid, so 32 unions of the (slice, lane quarter) groups serve
   // as well as the 512 groups the launch ranked (~15 % more candidates).
   float* tau_s = (float*)(smem + (SCAN_NS - 1) * 2 * 32 * 256 * 2);   // in the LAST ring slot: first written by the copies behind the loop's first barrier
   if (!SAMPLE) {
@@ -437,58 +443,57 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     }
     __syncthreads();
   }
-  uint4 qf[QB][16];
-  float tau[QB], gmax[QB];
-  int ncand[QB];
-  const int nstreams = a.nsplit * 2;
+  uint4 qf[NQ][8];
+  float tau[NQ], gmax[NQ];
+  int ncand[NQ];
+  const int nstreams = a.nsplit * 4;                   // a stream = (query, gallery slice, lane quarter rq)
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    // K-fragments from the fragment-major image sim_prep wrote (query block, K-step, lane) x 16 B: 1 KiB per wave-instruction,
-    // 16 of them per query block (reading the fp32 rows cost every CU 512 KiB of L2 traffic per launch: ~7 us)
-    const uint4* qimg = a.qimg + ((long)(q0 / 32 + qb) * 16) * 64 + lane;
+  for (int qb = 0; qb < NQ; ++qb) {
+    // K-fragments from the fragment-major image sim_prep wrote (16-query block, 32-deep K-step, lane) x 16 B: 1 KiB per wave-instruction,
+    // 8 of them per query block (reading the fp32 rows cost every CU 512 KiB of L2 traffic per launch: ~7 us)
+    const uint4* qimg = a.qimg + ((long)(q0 / 16 + qb) * 8) * 64 + lane;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) qf[qb][c] = active ? qimg[c * 64] : make_uint4(0, 0, 0, 0);
-    const int q = min(q0 + qb * 32 + r, a.Bq - 1);
-    tau[qb] = SAMPLE ? 0.f : tau_s[wave * (32 * QB) + qb * 32 + r] + a.tau_add;
+    for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = active ? qimg[kk * 64] : make_uint4(0, 0, 0, 0);
+    tau[qb] = SAMPLE ? 0.f : tau_s[wave * (32 * QB) + qb * 16 + n16] + a.tau_add;
     gmax[qb] = -INFINITY; ncand[qb] = 0;
   }
-  // read address of K-step c: row r, chunk (2c + h) ^ (r & 15) = ((c ^ (r>>1 & 7)) << 1) | ((h ^ r) & 1): one XOR per read instead
-  // of 16 address registers
-  const int rd_base = r * 512 + (((h ^ r) & 1) << 4), rd_x = (r >> 1) & 7;
-#define SIM_RD(c_) (rd_base + ((((c_) ^ rd_x)) << 5))
+  // read address of 32-deep K-step kk, row block rb: row rb * 16 + n16, chunk (4 kk + rq) ^ n16 = ((kk ^ (n16 >> 2)) << 2) | (rq ^ (n16 & 3)): one XOR
+  // per read. Conflict-free ds_read_b128: every 16-lane service group holds 16 different n16 (the two K quarters it mixes map onto disjoint slots).
+  const int rd_base = n16 * 512 + ((rq ^ (n16 & 3)) << 4), rd_x = n16 >> 2;
+#define SIM_RD(rb_, kk_) (rd_base + (rb_) * 8192 + ((((kk_) ^ rd_x)) << 6))
 
-  f32x16 acc[QB];
+  f32x4 acc[NQ][2];                                    // [16-query block][16-row block]: register e = row 4 rq + e of the row block
   // epilogue of one 32-row tile (rows g0 ..): SAMPLE keeps the group maximum; APPEND compares the tile maximum with tau and
   // appends the rare scores >= tau to the lane's private stream list
-  const int h4 = 4 * h;
+  const int r4 = 4 * rq;
   auto epilogue = [&](int g0) {
     const int lim = a.Ng - g0;                         // rows of this tile inside the shard (scalar); < 32 only at the shard's end
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    for (int qb = 0; qb < NQ; ++qb) {
       if (lim < 32) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (h4 + ((e & 3) + 8 * (e >> 2)) >= lim) acc[qb][e] = -INFINITY;          // clamped duplicate rows never count
-      }
-      float tmax = max3f(acc[qb][0], acc[qb][1], acc[qb][2]);
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int e = 3; e < 15; e += 2) tmax = max3f(tmax, acc[qb][e], acc[qb][e + 1]);
-      tmax = fmaxf(tmax, acc[qb][15]);
+          for (int e = 0; e < 4; ++e)
+            if (16 * rb + r4 + e >= lim) acc[qb][rb][e] = -INFINITY;                 // clamped duplicate rows never count
+      }
+      float tmax = max3f(acc[qb][0][0], acc[qb][0][1], acc[qb][0][2]);
+      tmax = max3f(tmax, acc[qb][0][3], acc[qb][1][0]);
+      tmax = max3f(tmax, acc[qb][1][1], acc[qb][1][2]);
+      tmax = fmaxf(tmax, acc[qb][1][3]);
       if (SAMPLE) {
         gmax[qb] = fmaxf(gmax[qb], tmax);
       } else if (__builtin_amdgcn_ballot_w64(tmax >= tau[qb]) != 0) {
-        // Some lane of the wave has a candidate in this tile (about every third tile and query block at 512 x 1M). Testing
-        // the 16 registers one by one cost ~80 instructions per triggered tile (70 us of a 270-us scan); instead a lane
-        // whose tile maximum passes appends its WHOLE 16-score column as one record (4 x 16-byte stores + the tile's first
-        // row) to its private stream list, and sim_final filters the records against tau: ~20 instructions, no inner branch.
-        int q = q0 + qb * 32 + r;
+        // Some lane of the wave has a candidate in this tile. Testing the registers one by one cost ~80 instructions per triggered tile
+        // (70 us of a 270-us scan in round 2); instead a lane whose tile maximum passes appends its WHOLE 8-score column as one record
+        // (2 x 16-byte stores + the tile's first row) to its private stream list, and sim_final filters the records against tau.
+        int q = q0 + qb * 16 + n16;
         asm volatile("" : "+v"(q));                    // opaque: keeps the list address arithmetic HERE (hoisted out of the tile loop
         if (tmax >= tau[qb] && q < a.Bq) {             // it was spilled, and a spill reload inside the loop drains the DMA ring)
           if (ncand[qb] < a.cap) {
-            const long rec = ((long)q * nstreams + split * 2 + h) * a.cap + ncand[qb];
-            f32x4* dst = (f32x4*)(a.rec_s + rec * 16);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dst[g] = f32x4{acc[qb][4 * g], acc[qb][4 * g + 1], acc[qb][4 * g + 2], acc[qb][4 * g + 3]};
+            const long rec = ((long)q * nstreams + split * 4 + rq) * a.cap + ncand[qb];
+            f32x4* dst = (f32x4*)(a.rec_s + rec * 8);
+            dst[0] = acc[qb][0]; dst[1] = acc[qb][1];
             a.rec_g[rec] = g0;
           }
           ++ncand[qb];
@@ -497,29 +502,29 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
     }
   };
   auto mfma_tile = [&](const char* buf) {
-    f32x16 zero;                                       // C operand of the first K-step: the inline constant 0 (no 32 v_mov per tile)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};           // C operand of the first K-step: the inline constant 0 (no v_mov per tile)
+    uint4 af[4];                                       // A fragments two K-steps (four reads) ahead of the MFMAs that consume them
 #pragma unroll
-    for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-    uint4 af[4];                                       // A fragments four K-steps ahead of the MFMAs that consume them
+    for (int i = 0; i < 4; ++i) af[i] = *(const uint4*)(buf + SIM_RD(i & 1, i >> 1));
 #pragma unroll
-    for (int c = 0; c < 4; ++c) af[c] = *(const uint4*)(buf + SIM_RD(c));
+    for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const uint4 av = af[c & 3];
-      if (c + 4 < 16) af[c & 3] = *(const uint4*)(buf + SIM_RD(c + 4));
+      for (int rb = 0; rb < 2; ++rb) {
+        const uint4 av = af[(2 * kk + rb) & 3];
+        if (kk + 2 < 8) af[(2 * kk + rb) & 3] = *(const uint4*)(buf + SIM_RD(rb, kk + 2));
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        if (__is_same(TG, bf16_t))
-          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][c]), c == 0 ? zero : acc[qb], 0, 0, 0);
-        else
-          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][c]), c == 0 ? zero : acc[qb], 0, 0, 0);
+        for (int qb = 0; qb < NQ; ++qb) {
+          if (__is_same(TG, bf16_t))
+            acc[qb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, qf[qb][kk]), kk == 0 ? zero : acc[qb][rb], 0, 0, 0);
+          else
+            acc[qb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, qf[qb][kk]), kk == 0 ? zero : acc[qb][rb], 0, 0, 0);
+        }
       }
-    }
   };
 
   // (s_setprio 1 for the younger half - waves 4-7 - before the loop, the guide's static-priority item, and a sample stride of 32 instead of 16
-  // at 1M rows: no difference in a same-box A/B - 320-333 us for all three builds on a box where this clock-bound kernel runs 20 % slower than
-  // on the round's other boxes, 268-272; a first cross-box comparison had read the box as the change. Not kept.)
+  // at 1M rows: no difference in a same-box A/B on the round-4 kernel. Round 5, measured with cycle stamps: priority 2 for the younger half
+  // during its FIRST tile only balances the two halves, below.)
   int g_pending = -1;                                  // late waves: tile whose epilogue is still owed
 #ifdef COR_PROBES
 #define SC_STAMP(i_) do { if (!SAMPLE && a.stamps && blockIdx.x == 0 && (tid & 255) == 0 && t - t0 < 24) { __builtin_amdgcn_sched_barrier(0); \
@@ -569,19 +574,19 @@ __global__ void __launch_bounds__(512, 2) sim_scan(const TG* __restrict__ G, con
 #undef SIM_RD
   if (active) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const int q = q0 + qb * 32 + r;
+    for (int qb = 0; qb < NQ; ++qb) {
+      const int q = q0 + qb * 16 + n16;
       if (q < a.Bq) {
-        if (SAMPLE) atomicMax(a.sg + (long)((split * 2 + h) & 31) * a.Bqp + q, f2key(gmax[qb]));     // (a group without a tile: key(-inf) > 0 = empty)
-        else a.cnt[(long)q * nstreams + split * 2 + h] = ncand[qb];
+        if (SAMPLE) atomicMax(a.sg + (long)((split * 4 + rq) & 31) * a.Bqp + q, f2key(gmax[qb]));    // (a group without a tile: key(-inf) > 0 = empty)
+        else a.cnt[(long)q * nstreams + split * 4 + rq] = ncand[qb];
       }
     }
   }
 }
 
-// Queries rounded to the gallery dtype in MFMA-fragment order: image[(qblk * 16 + c) * 64 + lane] = 16 B = q[qblk*32 + (lane&31)]
-// [16c + 8(lane>>5) .. +8]; rows beyond Bq repeat the last query (their results are never written). Also clears the per-call
-// overflow flags. One block of 256 threads per 32 queries.
+// Queries rounded to the gallery dtype in the fragment order of v_mfma_f32_16x16x32: image[(qblk16 * 8 + kk) * 64 + lane] = 16 B =
+// q[qblk16*16 + (lane&15)][32 kk + 8 (lane>>4) .. +8]; rows beyond Bq repeat the last query (their results are never written). Also
+// clears the per-call overflow flags. One block of 256 threads per 32 queries.
 template <typename TG>
 __global__ void __launch_bounds__(256) sim_prep(const float* __restrict__ Q, int Bq, uint4* img, int* flags, int* ovf_q, unsigned* sg, int Bqp,
                                                 float* dq) {
@@ -595,8 +600,9 @@ __global__ void __launch_bounds__(256) sim_prep(const float* __restrict__ Q, int
   for (int i = 0; i < 4; ++i) {
     const int item = tid + 256 * i, c = item >> 6, lane = item & 63, r = lane & 31, h = lane >> 5;
     const float* qrow = Q + (long)min(qblk * 32 + r, Bq - 1) * 256;
-    const uint4 f = q_frag16<TG>(qrow, c, h);
-    img[((long)qblk * 16 + c) * 64 + lane] = f;
+    const uint4 f = q_frag16<TG>(qrow, c, h);           // chunk ch = 2 c + h of the query: values 8 ch .. 8 ch + 7
+    // v_mfma_f32_16x16x32 fragment order: image[(qblk16 * 8 + kk) * 64 + lane'] with lane' = 16 * (ch & 3) + (query & 15), kk = ch >> 2
+    { const int ch = 2 * c + h; img[((long)(qblk * 2 + (r >> 4)) * 8 + (ch >> 2)) * 64 + 16 * (ch & 3) + (r & 15)] = f; }
     float n2 = 0.f;                                    // of the values as the MFMA sees them
     const uint32_t w[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
@@ -733,41 +739,62 @@ __global__ void __launch_bounds__(256) sim_final(const float* __restrict__ Q, co
   if (lane == 0) qn2[wave] = part;
   __syncthreads();
   const float delta = SIM_DELTA * fmaxf(1.f, sqrtf(qn2[0] + qn2[1] + qn2[2] + qn2[3]));
-  // 1. the private stream lists hold whole 16-score columns (records): keep the scores >= tau_q (the admission threshold of
-  // the scan, delta already subtracted) and compact them into LDS. Register e of lane half h is row g0 + (e&3) + 8 (e>>2) + 4 h.
+  // 1. the private stream lists hold whole 8-score columns (records: two 16-row blocks x four rows of one lane quarter): keep the scores
+  // >= tau_q (the admission threshold of the scan, delta already subtracted) and compact them into LDS. Score [g][i] of lane quarter rq is
+  // row g0 + 16 g + 4 rq + i.
   const float tq = tau[q];
-  auto take = [&](const f32x4 (&v)[4], int g0, int h4) {            // ONE returning LDS atomic per record (round 2: one per passing score,
+  auto take = [&](const f32x4 (&v)[2], int g0, int r4) {            // ONE returning LDS atomic per record (round 2: one per passing score,
     int np = 0;                                                       // up to 16 dependent LDS round trips per record)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) np += (v[g][i] >= tq && v[g][i] > -INFINITY) ? 1 : 0;
     if (np == 0) return;
     int p = atomicAdd(&total, np);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (v[g][i] >= tq && v[g][i] > -INFINITY) {
-          if (p < FS_MAX) { cs[p] = v[g][i]; ci[p] = g0 + i + 8 * g + h4; }
+          if (p < FS_MAX) { cs[p] = v[g][i]; ci[p] = g0 + i + 16 * g + r4; }
           ++p;
         }
   };
-  for (int st = tid; st < nstreams; st += 256) {
-    // record 0 of every stream is fetched TOGETHER with the stream's count (most streams hold 0 or 1 records): one global
-    // round trip instead of three dependent ones; its contents are ignored when the count is 0
-    const long rec0 = ((long)q * nstreams + st) * cap;
-    const f32x4* src = (const f32x4*)(rec_s + rec0 * 16);
-    const f32x4 v0[4] = {src[0], src[1], src[2], src[3]};
-    const int g00 = rec_g[rec0];
-    const int c = cnt[(long)q * nstreams + st];
-    if (c > cap) ovf = 1;
-    const int n = min(c, cap), h4 = 4 * (st & 1);
-    if (n > 0) take(v0, g00, h4);
-    for (int j = 1; j < n; ++j) {
-      const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 16);
-      const f32x4 vj[4] = {sj[0], sj[1], sj[2], sj[3]};
-      take(vj, rec_g[rec0 + j], h4);
+  // Two round trips: the thread's (up to four: 1024 streams) COUNTS first - contiguous per query, coalesced - then record 0 of its non-empty
+  // streams, all issued together. (Rounds 3-4 fetched record 0 WITH the count, one trip: with 1000 mostly empty streams per query that is
+  // 2 000 scattered 32-byte sectors per query, 64 MB per 512-query search: 5.5 us slower than this at 32k-125k rows.)
+  for (int st0 = 0; st0 < nstreams; st0 += 1024) {
+    int cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int st = st0 + 256 * u + tid;
+      cc[u] = st < nstreams ? cnt[(long)q * nstreams + st] : 0;
+    }
+    f32x4 v0[4][2]; int g00[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int st = st0 + 256 * u + tid;
+      if (cc[u] > 0) {
+        const long rec0 = ((long)q * nstreams + st) * cap;
+        const f32x4* src = (const f32x4*)(rec_s + rec0 * 8);
+        v0[u][0] = src[0]; v0[u][1] = src[1];
+        g00[u] = rec_g[rec0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int st = st0 + 256 * u + tid;
+      if (cc[u] > cap) ovf = 1;
+      const int n = min(cc[u], cap), r4 = 4 * (st & 3);
+      if (n > 0) take(v0[u], g00[u], r4);
+      if (n > 1) {
+        const long rec0 = ((long)q * nstreams + st) * cap;
+        for (int j = 1; j < n; ++j) {
+          const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 8);
+          const f32x4 vj[2] = {sj[0], sj[1]};
+          take(vj, rec_g[rec0 + j], r4);
+        }
+      }
     }
   }
   __syncthreads();
@@ -1230,7 +1257,7 @@ __global__ void __launch_bounds__(512, 2) sim_block_scan(const float* __restrict
 
 // ONE WAVE per query: gather the candidates, select, re-score exactly, rank. Two gather front ends: RECORDS = false: the
 // per-(query, slice) entry lists of sim_block_scan (cnt / cand; nl = slices); RECORDS = true: the per-(query, stream) records of
-// sim_scan<APPEND> (cnt / rec_s / rec_g; nl = streams; a record = the 16 scores of one lane's accumulator column + the tile's
+// sim_scan<APPEND> (cnt / rec_s / rec_g; nl = streams; a record = the 8 scores of one lane's accumulator column + the tile's
 // first row; the scores >= tau_q are kept).
 template <typename TG, bool RECORDS>
 __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q, const TG* __restrict__ G, const int* __restrict__ cnt,
@@ -1259,38 +1286,38 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
   __shared__ bool sovf[SB_MAXSL];
   if (RECORDS) {
     // 1r. lane <-> stream; record 0 of every stream is fetched TOGETHER with the stream's count (most streams hold 0 or 1 records):
-    // one global round trip instead of three dependent ones. Register e of lane half h4 / 4 is row g0 + (e&3) + 8 (e>>2) + h4.
+    // one global round trip instead of three dependent ones. Score [g][i] of lane quarter r4 / 4 is row g0 + 16 g + r4 + i.
     __shared__ int total;
     if (lane == 0) total = 0;
     __syncthreads();
     const float tq = tau[q];
-    auto take = [&](const f32x4 (&v)[4], int g0, int h4) {          // one LDS atomic per record (not per score), then predicated stores
+    auto take = [&](const f32x4 (&v)[2], int g0, int r4) {          // one LDS atomic per record (not per score), then predicated stores
       int np = 0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) np += (v[g][i] >= tq && v[g][i] > -INFINITY) ? 1 : 0;
       if (np == 0) return;
       int pos = atomicAdd(&total, np);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (v[g][i] >= tq && v[g][i] > -INFINITY) {
-            if (pos < SB_NC) { cs[pos] = v[g][i]; ci[pos] = g0 + i + 8 * g + h4; }
+            if (pos < SB_NC) { cs[pos] = v[g][i]; ci[pos] = g0 + i + 16 * g + r4; }
             ++pos;
           }
     };
-    // the loads of up to 8 streams per lane (512 streams) are issued together: one global round trip, not one per 64 streams
+    // the loads of up to 8 streams per lane (512 of up to 1024 streams) are issued together: one global round trip, not one per 64 streams
     constexpr int RS = 8;
     for (int sb = 0; sb < nslices; sb += 64 * RS) {
-      f32x4 v0[RS][4]; int g00[RS], cc[RS];
+      f32x4 v0[RS][2]; int g00[RS], cc[RS];
 #pragma unroll
       for (int u = 0; u < RS; ++u) {
         const int st = sb + 64 * u + lane;
         const long rec0 = ((long)q * nslices + (st < nslices ? st : 0)) * cap;
-        const f32x4* src = (const f32x4*)(rec_s + rec0 * 16);
-        v0[u][0] = src[0]; v0[u][1] = src[1]; v0[u][2] = src[2]; v0[u][3] = src[3];
+        const f32x4* src = (const f32x4*)(rec_s + rec0 * 8);
+        v0[u][0] = src[0]; v0[u][1] = src[1];
         g00[u] = rec_g[rec0];
         cc[u] = st < nslices ? cnt[(long)q * nslices + st] : 0;
       }
@@ -1298,14 +1325,14 @@ __global__ void __launch_bounds__(64) sim_final_wave(const float* __restrict__ Q
       for (int u = 0; u < RS; ++u) {
         const int st = sb + 64 * u + lane;
         if (cc[u] > cap) ovf = true;
-        const int nrec = min(cc[u], cap), h4 = 4 * (st & 1);
-        if (nrec > 0) take(v0[u], g00[u], h4);
+        const int nrec = min(cc[u], cap), r4 = 4 * (st & 3);
+        if (nrec > 0) take(v0[u], g00[u], r4);
         if (nrec > 1) {
           const long rec0 = ((long)q * nslices + st) * cap;
           for (int j = 1; j < nrec; ++j) {
-            const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 16);
-            const f32x4 vj[4] = {sj[0], sj[1], sj[2], sj[3]};
-            take(vj, rec_g[rec0 + j], h4);
+            const f32x4* sj = (const f32x4*)(rec_s + (rec0 + j) * 8);
+            const f32x4 vj[2] = {sj[0], sj[1]};
+            take(vj, rec_g[rec0 + j], r4);
           }
         }
       }
@@ -1454,16 +1481,16 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
   p.nqg = cdiv(Bq, 256 * p.qb);
   p.tiles = cdiv(Ng, 64);                              // 64-row super-tiles
   int want = device_cus() / p.nqg;                     // one resident block per CU
-  if (want > 256) want = 256;                          // nstreams <= 512
+  if (want > 256) want = 256;                          // nstreams <= 1024
   if (want > p.tiles) want = p.tiles;
   if (want < 1) want = 1;
   p.tiles_per_split = cdiv(p.tiles, want);
   p.nsplit = cdiv(p.tiles, p.tiles_per_split);
-  p.nstreams = 2 * p.nsplit;
+  p.nstreams = 4 * p.nsplit;                           // (query, slice, lane quarter)
   long expect;                                         // expected accepted scores per query over the whole shard
   if (Ng <= 4096) {                                    // tiny shard: no sample pass, every row is a candidate (<= FS_MAX)
     p.ngroups = 0; p.s_tiles = 0; p.s_stride = 1; p.s_nsplit = 0; p.s_tiles_per_split = 0;
-    p.cap = 2 * p.tiles_per_split;                     // records (32-row tiles) per (slice, lane half) stream: every tile is one
+    p.cap = 2 * p.tiles_per_split;                     // records (32-row tiles) per (slice, lane quarter) stream: every tile is one
   } else {
     // every 16th super-tile, at least ~128 of them: the sample pass costs 1/stride of the full scan plus a fixed ~8 us; the
     // candidates it admits (~2 k stride per query) must stay rare per wave and tile (the append path is divergent)
@@ -1475,7 +1502,7 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
     if (sw < 1) sw = 1;
     p.s_tiles_per_split = cdiv(p.s_tiles, sw);
     p.s_nsplit = cdiv(p.s_tiles, p.s_tiles_per_split);
-    p.ngroups = 2 * p.s_nsplit;
+    p.ngroups = 4 * p.s_nsplit;
     expect = 3L * k * p.s_stride;                      // ~ k * Ng / sample rows, x3 for group-maximum slack
     // k > 16: tau is the k-th largest of only 32 super-group maxima - near k = 32 their MINIMUM, which admits ~4x the candidates of the
     // tighter bound the factor 3 was sized for: without this most searches overflow some stream and fall back (exact, slow)
@@ -1493,7 +1520,7 @@ inline V3Plan make_v3(int Bq, int Ng, int k) {
   p.off_flags = take(16);
   p.off_ovf = take((size_t)Bq * 4);
   p.off_cnt = take((size_t)Bq * p.nstreams * 4);
-  p.off_recs = take((size_t)Bq * p.nstreams * p.cap * 64);
+  p.off_recs = take((size_t)Bq * p.nstreams * p.cap * 32);            // a record = 8 scores
   p.off_recg = take((size_t)Bq * p.nstreams * p.cap * 4);
   p.off_lists = take((size_t)Bq * p2.nparts * p2.kmax * 8);          // fallback list kernels
   p.bytes = o;
