@@ -667,6 +667,9 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
 #define PP_STAMP(i_) do { } while (0)
 #endif
     PP_STAMP(0);
+#ifdef COR_PROBES
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[qi * 16 + 13] = __builtin_amdgcn_s_memrealtime();     // 100 MHz: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+#endif
     // B(0), A(0) landed: younger = A(1), B(1) (8 LDS-DMA) and the previous tile's buffer stores
     if (stores_pending) {
       if constexpr (NSTORE == 16) { if (nkt > 1) COR_VMCNT(24); else COR_VMCNT(16); }
@@ -834,7 +837,7 @@ __global__ void __launch_bounds__(512, 1) gemm_pp(const GemmArgs g) {
     }
 #undef COR_EPI
 #ifdef COR_PROBES
-    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[(qi - 1) * 16 + 15] = __builtin_readcyclecounter();
+    if (g.stamps && blockIdx.x == 0 && tid == 0) { g.stamps[(qi - 1) * 16 + 15] = __builtin_readcyclecounter(); g.stamps[(qi - 1) * 16 + 14] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     if (Ln < 0) break;
     L = Ln;

@@ -23,9 +23,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = st.view(torch.int64)[:16 * 32].cpu().view(-1, 16)
 names = ["start", "kloop", "realign", "bias", "pre"] + [f"blk{i}" for i in range(8)] + ["", "", "end"]
+rows_ = [r for r in t.tolist() if r[0]]
+if rows_ and rows_[0][13] and rows_[-1][14]:
+    dc, dr = rows_[-1][15] - rows_[0][0], rows_[-1][14] - rows_[0][13]
+    print(f"in-kernel clock: {dc} cycles (s_memtime) in {dr} ticks of s_memrealtime (100 MHz) = {dc / dr * 0.1:.3f} GHz over {dr / 100:.1f} us, {len(rows_)} tiles")
 for ti in range(t.shape[0]):
     row = t[ti].tolist()
     if row[0] == 0: continue
+    row[13] = row[14] = 0
     base = row[0]
     print(f"tile {ti}: " + " ".join(f"{names[i]}+{(row[i] - (row[i - 1] if i and row[i - 1] else base))}" for i in range(16) if row[i]))
     print(f"        total {row[15] - base} counter units; K loop {row[1] - base}, epilogue {row[15] - row[2]}")
