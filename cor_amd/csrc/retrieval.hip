@@ -299,8 +299,8 @@ __global__ void __launch_bounds__(256, 1) sim_topk_v2(const float* __restrict__ 
 //      32 unions admit ~15 % more candidates and cost the prologue ~3 us: one launch fewer, 0-2 % faster in a same-box A/B.
 //   C. sim_scan<APPEND>: MFMA scores of the WHOLE shard; a lane compares its tile maximum with tau_q and appends the rare
 //      scores >= tau_q to the private list of its (query, gallery slice, lane quarter) stream (register counter, no atomics).
-//   D. sim_final: per query, the candidates are compacted into LDS, the k-th best MFMA score T is found by a 4-pass radix
-//      select, the SHORT LIST (MFMA score >= T - delta_q, ~k entries) is RE-SCORED with the exact fp32 fmaf chain of
+//   D. sim_final: per query, the candidates are compacted into LDS, the k-th best MFMA score T is bounded by a 2-pass radix
+//      select (16 key bits), the SHORT LIST (MFMA score >= T - delta_q, ~k entries) is RE-SCORED with the exact fp32 fmaf chain of
 //      oracle/c/sim_chain.c over the stored 16-bit values (the query rounded to the gallery dtype), and ranked by
 //      (chain score desc, index asc).
 // Exactness. Let s~ be the MFMA score (fp32 accumulation of exact bf16/fp16 products in the matrix core's order) and s the
@@ -336,8 +336,9 @@ struct ScanArgs {
 // One block = 8 waves = 256 * QB queries (wave w owns queries q0 + 32 * QB * w ..): with QB = 2 all 512 queries of an
 // 8-GPU all-gather (8 x 64) sit in ONE block, so every gallery byte is fetched from HBM once per launch (512 MB at 1M rows)
 // and the kernel is MFMA-bound (arithmetic intensity = queries per block FLOP/B against a ridge of ~400); the K-fragments of
-// the wave's queries stay in registers for the whole kernel (QB * 64 VGPRs) and each A fragment read from LDS feeds QB MFMAs.
-// Gallery super-tiles (64 rows x 512 B = two MFMA tiles) stream through a 4-slot LDS-DMA ring, 3 of them (96 KiB per CU) in
+// the wave's queries stay in registers for the whole kernel (QB * 64 VGPRs) and each A fragment read from LDS feeds 2 QB MFMAs
+// (v_mfma_f32_16x16x32 since round 5: see the kernel).
+// Gallery super-tiles (64 rows x 512 B = two 32-row tiles) stream through a 5-slot LDS-DMA ring, 4 of them (128 KiB per CU) in
 // flight: counted s_waitcnt vmcnt, ONE barrier per 64 rows. The LDS image is lane-linear per wave-instruction (64 lanes x 16 B = two 512-B
 // rows), so slot (row, sl) is fed from source chunk sl ^ (row & 15) and the reads apply the same XOR (conflict-free b128).
 // max of three. NOT inline asm: hipcc pads no MFMA -> VALU read hazard for an asm statement, so a v_max3_f32 in asm read the
